@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by importing the reference (THIS container only).
+
+    python tests/golden/make_golden.py static     -> tests/golden/static.npz
+    python tests/golden/make_golden.py dnerf      -> tests/golden/dnerf.npz
+
+The reference (a pure-Python/PyTorch project at /root/reference) cannot travel to the GPU box, so
+its outputs on seeded synthetic inputs are frozen here as data.  Inputs come from
+tests/nerf_fixtures.py (numpy, seed-driven) so the tests can rebuild the weights instead of
+storing 2.4 MB per network.  `imageio` (PNG/MP4 writing only; render.py:6) is absent from the image
+and is replaced by an empty module object before import; nothing on the measured path touches it.
+Static and D-NeRF stacks use colliding bare module names (render, network, ...) and therefore run
+in separate processes.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import nerf_fixtures as fx  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _meta(torch):
+    return np.array([torch.__version__, torch.backends.cpu.get_cpu_capability(),
+                     str(torch.get_num_threads())])
+
+
+def _load(torch, module, sd):
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return module
+
+
+def grad_summary(g):
+    """Compact, order-sensitive summary of a gradient tensor: [sum, l2, strided subsample(256)]."""
+    g = g.detach().reshape(-1).double().numpy()
+    idx = np.linspace(0, g.size - 1, min(256, g.size)).astype(np.int64)
+    return np.concatenate([[g.sum(), np.sqrt((g * g).sum())], g[idx]])
+
+
+def gen_static(out):
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, REF)
+    import torch
+    import positional_encoding as pe
+    import network
+    import sampling
+    import render as rr
+    import rays as rays_mod
+    from utils import img2mse
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    T = torch.from_numpy
+    rng = np.random.RandomState(1234)
+
+    # ---- A1 positional encoding (positional_encoding.py:5-64)
+    x = np.concatenate([rng.uniform(-6, 6, (200, 3)), rng.uniform(-1, 1, (100, 3)),
+                        np.array([[0, 0, 0], [6, -6, 2.5], [1e-3, 1e-6, -4.0]])]).astype(np.float32)
+    G["pe_x"] = x
+    e10, d10 = pe.get_embedder(10, 0)
+    e4, d4 = pe.get_embedder(4, 0)
+    assert (d10, d4) == (63, 27)
+    G["pe10"] = e10(T(x)).numpy()
+    G["pe4"] = e4(T(x)).numpy()
+    x2 = rng.uniform(0, 1, (64, 2)).astype(np.float32)
+    emb2 = pe.Embedder(include_input=True, input_dims=2, max_freq_log2=5, num_freqs=6, log_sampling=True,
+                       periodic_fns=[torch.sin, torch.cos])
+    G["pe2d_x"] = x2
+    G["pe2d_L6"] = emb2.embed(T(x2)).numpy()
+    emb_lin = pe.Embedder(include_input=False, input_dims=3, max_freq_log2=3, num_freqs=5, log_sampling=False,
+                          periodic_fns=[torch.sin, torch.cos])
+    G["pe_lin_noinput"] = emb_lin.embed(T(x[:64])).numpy()
+
+    # ---- A2 NeRF forward (network.py:46-69)
+    pts = rng.uniform(-3, 3, (384, 3)).astype(np.float32)
+    dirs = rng.normal(size=(384, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    G["mlp_pts"], G["mlp_dirs"] = pts, dirs
+    xin = torch.cat([e10(T(pts)), e4(T(dirs))], -1)
+    G["mlp_x"] = xin.numpy()
+    with torch.no_grad():
+        for name, seed, peaky in (("default", 11, False), ("peaky", 12, True)):
+            net = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(seed, peaky=peaky))
+            G[f"mlp_out_{name}"] = net(xin).numpy()
+        # small no-viewdirs variant (model.py:26-34 with use_viewdirs=False: input_ch_views=0, output_ch=5)
+        sd = fx.make_nerf_state(13, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=5, skips=(2,),
+                                use_viewdirs=False)
+        net = _load(torch, network.NeRF(4, 128, 63, 0, 5, [2], False), sd)
+        G["mlp_out_noview"] = net(xin[:, :63]).numpy()
+
+    # ---- A6 raw2outputs (render.py:82-131) + autograd grads of a scalar of (rgb_map, ...)
+    for name, S, wb in (("s64_white", 64, True), ("s192", 192, False), ("s7", 7, True)):
+        n = 48
+        raw = (rng.normal(size=(n, S, 4)) * np.array([1, 1, 1, 4.0])).astype(np.float32)
+        raw[0, :, 3] = -1.0       # fully transparent ray
+        raw[1, S // 2, 3] = 1e4   # an opaque wall: alpha == 1 exactly -> exercises the +1e-10
+        z = np.sort(rng.uniform(2, 6, (n, S)).astype(np.float32), -1)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        rawt = T(raw).requires_grad_(True)
+        rgb, disp, acc, w, depth = rr.raw2outputs(rawt, T(z), T(d), 0, wb)
+        g_rgb = rng.normal(size=(n, 3)).astype(np.float32)
+        (rgb * T(g_rgb)).sum().backward()
+        G[f"r2o_{name}_raw"], G[f"r2o_{name}_z"], G[f"r2o_{name}_d"] = raw, z, d
+        G[f"r2o_{name}_rgb"], G[f"r2o_{name}_disp"], G[f"r2o_{name}_acc"] = \
+            rgb.detach().numpy(), disp.detach().numpy(), acc.detach().numpy()
+        G[f"r2o_{name}_w"], G[f"r2o_{name}_depth"] = w.detach().numpy(), depth.detach().numpy()
+        G[f"r2o_{name}_grgb"], G[f"r2o_{name}_graw"] = g_rgb, rawt.grad.numpy()
+
+    # ---- coarse z_vals / pts (render.py:186-210), perturb=0, lindisp both ways
+    for name, near, far, lindisp in (("blender", 2.0, 6.0, False), ("ndc", 0.0, 1.0, False),
+                                     ("lindisp", 0.5, 9.0, True)):
+        n = 40
+        nr = torch.full((n, 1), near) + 0 * T(rng.uniform(0, 1, (n, 1)).astype(np.float32))
+        fr = torch.full((n, 1), far)
+        if name == "lindisp":
+            nr = nr + T(rng.uniform(0, 1, (n, 1)).astype(np.float32))
+        t_vals = torch.linspace(0., 1., steps=64)
+        zv = nr * (1. - t_vals) + fr * t_vals if not lindisp else 1. / (1. / nr * (1. - t_vals) + 1. / fr * t_vals)
+        o = T(rng.uniform(-4, 4, (n, 3)).astype(np.float32))
+        d = T(rng.normal(size=(n, 3)).astype(np.float32))
+        p = o[..., None, :] + d[..., None, :] * zv[..., :, None]
+        G[f"zc_{name}_near"], G[f"zc_{name}_far"] = nr.numpy(), fr.numpy()
+        G[f"zc_{name}_o"], G[f"zc_{name}_d"] = o.numpy(), d.numpy()
+        G[f"zc_{name}_z"], G[f"zc_{name}_pts"] = zv.numpy(), p.numpy()
+    for n in (2, 3, 5, 64, 65, 128, 192):
+        G[f"linspace_{n}"] = torch.linspace(0., 1., steps=n).numpy()
+
+    # ---- A7 sample_pdf + merge (sampling.py:5-60, render.py:219-224, :238), det=True
+    n = 200
+    for name, near, far, peak in (("blender_p1", 2, 6, 1.0), ("blender_p6", 2, 6, 6.0), ("ndc_p30", 0, 1, 30.0)):
+        t_vals = torch.linspace(0., 1., steps=64)
+        zv = (near * (1. - t_vals) + far * t_vals).expand(n, 64)
+        w = np.abs(rng.normal(size=(n, 64))) ** peak
+        w = (w / w.sum(-1, keepdims=True)).astype(np.float32)
+        w[0] = 0.0                      # all-zero weights ray
+        w[1] = 0.0; w[1, 17] = 1.0      # one-hot
+        w[2] = 0.0; w[2, 1] = 0.5; w[2, 62] = 0.5
+        mids = .5 * (zv[..., 1:] + zv[..., :-1])
+        for nimp in (128, 64):
+            zs = sampling.sample_pdf(mids, T(w)[..., 1:-1], nimp, det=True)
+            zm, _ = torch.sort(torch.cat([zv, zs], -1), -1)
+            G[f"spdf_{name}_n{nimp}_zs"] = zs.numpy()
+            G[f"spdf_{name}_n{nimp}_zm"] = zm.numpy()
+            G[f"spdf_{name}_n{nimp}_std"] = torch.std(zs, dim=-1, unbiased=False).numpy()
+        G[f"spdf_{name}_z"], G[f"spdf_{name}_w"] = zv.numpy().copy(), w
+    # explicit-u variant (the pytest=True route is numpy f64 linspace -> torch.Tensor f32)
+    u = rng.uniform(0, 1, (n, 128)).astype(np.float32)
+    G["spdf_u"] = u
+
+    # ---- A8 render_rays (render.py:134-244) full dicts
+    def query_fn(embed, embeddirs, chunk=65536):
+        return lambda inputs, viewdirs, fn: rr.run_network(inputs, viewdirs, fn, embed, embeddirs, chunk)
+
+    coarse = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(21, peaky=True))
+    fine = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(22, peaky=True))
+    cases = {
+        "blender": dict(rays=fx.blender_rays(96, 5), white_bkgd=True, lindisp=False, N_importance=128),
+        "ndc": dict(rays=fx.ndc_like_rays(64, 6), white_bkgd=False, lindisp=False, N_importance=64),
+        "lindisp": dict(rays=fx.blender_rays(48, 7, near=1.0, far=8.0), white_bkgd=False, lindisp=True,
+                        N_importance=128),
+    }
+    with torch.no_grad():
+        for name, c in cases.items():
+            ret = rr.render_rays(T(c["rays"]), coarse, query_fn(e10, e4), 64, retraw=True, lindisp=c["lindisp"],
+                                 perturb=0., N_importance=c["N_importance"], network_fine=fine,
+                                 white_bkgd=c["white_bkgd"], raw_noise_std=0.)
+            G[f"rr_{name}_rays"] = c["rays"]
+            for k, v in ret.items():
+                G[f"rr_{name}_{k}"] = v.numpy()
+        # no viewdirs, no fine net (N_importance=0), 8-column rays
+        sd = fx.make_nerf_state(23, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,),
+                                use_viewdirs=False, peaky=True)
+        small = _load(torch, network.NeRF(4, 128, 63, 0, 4, [2], False), sd)
+        r8 = fx.blender_rays(32, 8, with_viewdirs=False)
+        ret = rr.render_rays(T(r8), small, query_fn(e10, None), 64, retraw=True, N_importance=0, white_bkgd=True)
+        G["rr_noview_rays"] = r8
+        for k, v in ret.items():
+            G[f"rr_noview_{k}"] = v.numpy()
+        # fine pass through the coarse net (network_fine=None, render.py:226)
+        ret = rr.render_rays(T(r8), small, query_fn(e10, None), 64, N_importance=32, network_fine=None,
+                             white_bkgd=False)
+        for k, v in ret.items():
+            G[f"rr_samefine_{k}"] = v.numpy()
+
+    # ---- A9 render() from a pose (render.py:247-315, rays.py:5-27, :52-83)
+    with torch.no_grad():
+        H = W = 12
+        K, focal = fx.intrinsics(H, W)
+        c2w = fx.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+        kw = dict(network_query_fn=query_fn(e10, e4), perturb=0., N_importance=128, network_fine=fine,
+                  N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.,
+                  ndc=False, lindisp=False)
+        rgb, disp, acc, extras = rr.render(H, W, K, chunk=100, c2w=T(c2w), near=2., far=6., **kw)
+        G["render_blender_c2w"], G["render_blender_K"] = c2w, K
+        G["render_blender_rgb"], G["render_blender_disp"], G["render_blender_acc"] = rgb.numpy(), disp.numpy(), acc.numpy()
+        G["render_blender_rgb0"], G["render_blender_z_std"] = extras["rgb0"].numpy(), extras["z_std"].numpy()
+        ro, rd = rays_mod.get_rays(H, W, K, T(c2w))
+        G["render_blender_rays_o"], G["render_blender_rays_d"] = ro.numpy().copy(), rd.numpy()
+        # NDC forward-facing
+        H, W = 9, 12
+        K, focal = fx.intrinsics(H, W, 0.9)
+        c2w = np.array([[1, 0, 0, 0.1], [0, 1, 0, -0.05], [0, 0, 1, 0.2]], np.float32)
+        kw.update(white_bkgd=False, ndc=True, N_importance=64)
+        rgb, disp, acc, extras = rr.render(H, W, K, chunk=50, c2w=T(c2w), near=0., far=1., **kw)
+        G["render_ndc_c2w"], G["render_ndc_K"] = c2w, K
+        G["render_ndc_rgb"], G["render_ndc_disp"], G["render_ndc_acc"] = rgb.numpy(), disp.numpy(), acc.numpy()
+        ro, rd = rays_mod.get_rays(H, W, K, T(c2w))
+        ro, rd = rays_mod.ndc_rays(H, W, K[0][0], 1., ro, rd)
+        G["render_ndc_rays_o"], G["render_ndc_rays_d"] = ro.numpy(), rd.numpy()
+        # c2w_staticcam branch (render.py:286-288)
+        c2w_s = fx.pose_spherical(-60.0, -20.0, 4.0)[:3, :4]
+        H = W = 6
+        K, focal = fx.intrinsics(H, W)
+        kw.update(white_bkgd=True, ndc=False, N_importance=128)
+        rgb, _, _, _ = rr.render(H, W, K, chunk=1 << 15, c2w=T(G["render_blender_c2w"]), near=2., far=6.,
+                                 c2w_staticcam=T(c2w_s), **kw)
+        G["render_static_c2w"], G["render_static_rgb"] = c2w_s, rgb.numpy()
+
+    # ---- training step (train.py:226-243): loss + per-parameter grad summaries, 64-ray batch
+    ro, rd, target = fx.train_batch(64, seed=3)
+    batch_rays = torch.stack([T(ro), T(rd)], 0)
+    kw = dict(network_query_fn=query_fn(e10, e4), perturb=0., N_importance=128, network_fine=fine, N_samples=64,
+              network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+    H = W = 400
+    K, _ = fx.intrinsics(H, W)
+    for net in (coarse, fine):
+        net.zero_grad()
+    rgb, disp, acc, extras = rr.render(H, W, K, chunk=32768, rays=batch_rays, retraw=True, near=2., far=6., **kw)
+    loss = img2mse(rgb, T(target)) + img2mse(extras["rgb0"], T(target))
+    loss.backward()
+    G["train_ro"], G["train_rd"], G["train_target"] = ro, rd, target
+    G["train_loss"] = np.array([loss.item()])
+    G["train_rgb"], G["train_rgb0"] = rgb.detach().numpy(), extras["rgb0"].detach().numpy()
+    for tag, net in (("coarse", coarse), ("fine", fine)):
+        for k, p in net.named_parameters():
+            G[f"train_grad_{tag}_{k}"] = grad_summary(p.grad)
+
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
+def gen_dnerf(out):
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, os.path.join(REF, "vanilla_dynamic"))
+    import torch
+    import positional_encoding as pe
+    import network
+    import render as rr
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    T = torch.from_numpy
+    rng = np.random.RandomState(4321)
+
+    embed_fn, ich = pe.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, ichv = pe.get_embedder(4, 0, input_dims=3)
+    embed_time, icht = pe.get_time_embedder(10)
+    assert (ich, ichv, icht) == (63, 27, 21)
+    tt = rng.uniform(0, 1, (50, 1)).astype(np.float32)
+    G["time_x"], G["time_pe"] = tt, embed_time(T(tt)).numpy()
+    e_noinp, d_noinp = pe.get_embedder(4, 0, input_dims=3, include_input=False)
+    x = rng.uniform(-2, 2, (40, 3)).astype(np.float32)
+    G["pe_noinp_x"], G["pe_noinp"] = x, e_noinp(T(x)).numpy()
+
+    model = network.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                      input_ch_time=21, output_ch=4, skips=[4], use_viewdirs=True,
+                                      zero_canonical=True)
+    sd = fx.make_dnerf_state(31, peaky=True, dx_scale=3.0)
+    model.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    model.embed_fn = embed_fn
+
+    # D3 forward on points (network.py:307-341)
+    pts = rng.uniform(-2, 2, (256, 3)).astype(np.float32)
+    dirs = rng.normal(size=(256, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    G["fwd_pts"], G["fwd_dirs"] = pts, dirs
+    with torch.no_grad():
+        xin = torch.cat([embed_fn(T(pts)), embeddirs_fn(T(dirs))], -1)
+        for name, tval in (("t0", 0.0), ("t05", 0.5)):
+            t_raw = torch.full((256, 1), tval)
+            te = embed_time(t_raw)
+            out_, dx = model(xin, [te, te], pts_raw=T(pts), t_raw=t_raw)
+            G[f"fwd_{name}_out"], G[f"fwd_{name}_dx"] = out_.numpy(), dx.numpy()
+        # canonical net alone (D1 forward returns (out, zeros))
+        o, z = model._occ(xin)
+        G["occ_out"], G["occ_zeros"] = o.numpy(), z.numpy()
+
+    # D5 render_rays_dnerf (render.py:218-326)
+    qfn = lambda inputs, viewdirs, times, fn: rr.run_network_dnerf(  # noqa: E731
+        inputs, viewdirs, times, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, embed_time_fn=embed_time,
+        netchunk=65536, network_type="deformation")
+    rays = fx.blender_rays(48, 9)
+    G["rr_rays"] = rays
+    with torch.no_grad():
+        for name, tval in (("t0", 0.0), ("t05", 0.5)):
+            tv = torch.full((48, 1), tval)
+            ret = rr.render_rays_dnerf(T(rays), tv, model, qfn, 64, retraw=True, perturb=0., N_importance=128,
+                                       network_fine=None, white_bkgd=True)
+            for k, v in ret.items():
+                G[f"rr_{name}_{k}"] = v.numpy()
+        # per-ray times (train.py:132-161 route): first ray has t != 0 so the time net runs for all
+        tv = T(rng.uniform(0.1, 1, (48, 1)).astype(np.float32))
+        ret = rr.render_rays_dnerf(T(rays), tv, model, qfn, 64, retraw=False, perturb=0., N_importance=128,
+                                   network_fine=None, white_bkgd=True)
+        G["rr_tvar_times"] = tv.numpy()
+        for k, v in ret.items():
+            G[f"rr_tvar_{k}"] = v.numpy()
+        # render_dnerf from a pose with scalar time (render.py:368-433)
+        H = W = 8
+        K, focal = fx.intrinsics(H, W)
+        c2w = fx.pose_spherical(45.0, -30.0, 4.0)[:3, :4]
+        rgb, disp, acc, extras = rr.render_dnerf(
+            H, W, K, 0.25, chunk=40, c2w=T(c2w), near=2., far=6., use_viewdirs=True, network_fn=model,
+            network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None, white_bkgd=True,
+            raw_noise_std=0.)
+        G["render_c2w"], G["render_K"] = c2w, K
+        G["render_rgb"], G["render_disp"], G["render_acc"], G["render_dx"] = \
+            rgb.numpy(), disp.numpy(), acc.numpy(), extras["dx"].numpy()
+
+    # training grads through the deformation chain (train.py:238-276 minus clip/optimizer)
+    ro, rd, target = fx.train_batch(32, seed=4)
+    vd = rd / np.linalg.norm(rd, axis=-1, keepdims=True)
+    rays = np.concatenate([ro, rd, np.full((32, 1), 2, np.float32), np.full((32, 1), 6, np.float32), vd], -1).astype(np.float32)
+    tv = T(rng.uniform(0.1, 1, (32, 1)).astype(np.float32))
+    model.zero_grad()
+    ret = rr.render_rays_dnerf(T(rays), tv, model, qfn, 64, retraw=True, perturb=0., N_importance=128,
+                               network_fine=None, white_bkgd=True)
+    loss = torch.mean((ret["rgb_map"] - T(target)) ** 2) + torch.mean((ret["rgb0"] - T(target)) ** 2)
+    loss.backward()
+    G["train_rays"], G["train_times"], G["train_target"] = rays, tv.numpy(), target
+    G["train_loss"] = np.array([loss.item()])
+    for k, p in model.named_parameters():
+        G[f"train_grad_{k}"] = grad_summary(p.grad)
+
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    {"static": gen_static, "dnerf": gen_dnerf}[which](os.path.join(HERE, f"{which}.npz"))
