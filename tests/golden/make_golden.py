@@ -171,6 +171,24 @@ def gen_static(out):
             G[f"rr_{name}_rays"] = c["rays"]
             for k, v in ret.items():
                 G[f"rr_{name}_{k}"] = v.numpy()
+            # the intermediates render_rays does not return (coarse weights, merged z_vals), recomputed
+            # with the reference's own functions in the order of render.py:186-229; checked to
+            # reproduce the returned fine `raw` bit-for-bit.
+            rb = T(c["rays"])
+            o_, d_, vd_ = rb[:, 0:3], rb[:, 3:6], rb[:, -3:]
+            nr, fr = rb[:, 6:7], rb[:, 7:8]
+            tv = torch.linspace(0., 1., steps=64)
+            zv = nr * (1. - tv) + fr * tv if not c["lindisp"] else 1. / (1. / nr * (1. - tv) + 1. / fr * tv)
+            p_ = o_[..., None, :] + d_[..., None, :] * zv[..., :, None]
+            raw0 = query_fn(e10, e4)(p_, vd_, coarse)
+            _, _, _, w0, _ = rr.raw2outputs(raw0, zv, d_, 0, c["white_bkgd"])
+            zs = sampling.sample_pdf(.5 * (zv[..., 1:] + zv[..., :-1]), w0[..., 1:-1], c["N_importance"], det=True)
+            zf, _ = torch.sort(torch.cat([zv, zs], -1), -1)
+            p_ = o_[..., None, :] + d_[..., None, :] * zf[..., :, None]
+            raw1 = query_fn(e10, e4)(p_, vd_, fine)
+            assert torch.equal(raw1, ret["raw"])
+            G[f"rr_{name}_raw0"], G[f"rr_{name}_weights0"] = raw0.numpy(), w0.numpy()
+            G[f"rr_{name}_z_vals"] = zf.numpy()
         # no viewdirs, no fine net (N_importance=0), 8-column rays
         sd = fx.make_nerf_state(23, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,),
                                 use_viewdirs=False, peaky=True)
@@ -233,6 +251,18 @@ def gen_static(out):
     loss = img2mse(rgb, T(target)) + img2mse(extras["rgb0"], T(target))
     loss.backward()
     G["train_ro"], G["train_rd"], G["train_target"] = ro, rd, target
+    with torch.no_grad():   # intermediates (as for the rr_* cases): coarse weights and merged fine depths
+        o_, d_ = T(ro), T(rd)
+        vd_ = d_ / torch.norm(d_, dim=-1, keepdim=True)
+        tv = torch.linspace(0., 1., steps=64)
+        zv = (2. * torch.ones_like(d_[:, :1])) * (1. - tv) + (6. * torch.ones_like(d_[:, :1])) * tv
+        raw0 = query_fn(e10, e4)(o_[..., None, :] + d_[..., None, :] * zv[..., :, None], vd_, coarse)
+        _, _, _, w0, _ = rr.raw2outputs(raw0, zv, d_, 0, True)
+        zs = sampling.sample_pdf(.5 * (zv[..., 1:] + zv[..., :-1]), w0[..., 1:-1], 128, det=True)
+        zf, _ = torch.sort(torch.cat([zv, zs], -1), -1)
+        raw1 = query_fn(e10, e4)(o_[..., None, :] + d_[..., None, :] * zf[..., :, None], vd_, fine)
+        assert torch.equal(raw1, extras["raw"].detach())
+        G["train_weights0"], G["train_z_vals"] = w0.numpy(), zf.numpy()
     G["train_loss"] = np.array([loss.item()])
     G["train_rgb"], G["train_rgb0"] = rgb.detach().numpy(), extras["rgb0"].detach().numpy()
     for tag, net in (("coarse", coarse), ("fine", fine)):

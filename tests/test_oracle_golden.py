@@ -1,0 +1,277 @@
+"""Pin the oracle (oracle/) to the reference: every golden vector in tests/golden/*.npz was produced
+by importing /root/reference (tests/golden/make_golden.py).  Sample positions are checked BIT-EXACT
+(SURVEY 8a row N); network / compositing outputs to 1e-5 absolute (they feed a 1e-4 parity bar).
+CPU only -- runs without a GPU and without /root/reference."""
+import numpy as np
+import pytest
+
+import nerf_fixtures as fx
+from conftest import assert_bit_exact, assert_mostly_close
+from oracle import oracle as orc
+
+
+def test_linspace_bit_exact(gold):
+    for n in (2, 3, 5, 64, 65, 128, 192):
+        assert_bit_exact(orc.linspace(0., 1., n), gold[f"linspace_{n}"], f"linspace {n}")
+
+
+def test_embed(gold):
+    x = gold["pe_x"]
+    # sin/cos of exactly-representable arguments; libm vs ATen's vectorised sinf differ by <= 1 ulp
+    np.testing.assert_allclose(orc.embed(x, 10), gold["pe10"], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(orc.embed(x, 4), gold["pe4"], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(orc.embed(gold["pe2d_x"], 6), gold["pe2d_L6"], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(orc.embed(x[:64], 5, max_freq_log2=3, log_sampling=False, include_input=False),
+                               gold["pe_lin_noinput"], atol=2e-6, rtol=0)
+    # identity channels and channel order are exact
+    assert_bit_exact(orc.embed(x, 10)[:, :3], x, "include_input")
+
+
+@pytest.mark.parametrize("name,lindisp", [("blender", False), ("ndc", False), ("lindisp", True)])
+def test_coarse_positions_bit_exact(gold, name, lindisp):
+    n = gold[f"zc_{name}_near"].shape[0]
+    rays = np.concatenate([gold[f"zc_{name}_o"], gold[f"zc_{name}_d"], gold[f"zc_{name}_near"],
+                           gold[f"zc_{name}_far"]], -1)
+    z, pts = orc.sample_coarse(rays, 64, lindisp)
+    assert z.shape == (n, 64)
+    assert_bit_exact(z, gold[f"zc_{name}_z"], "z_vals")
+    assert_bit_exact(pts, gold[f"zc_{name}_pts"], "pts")
+
+
+def test_aten_row_sum_order():
+    # the 62-term sum of sample_pdf is order-sensitive; check a few lengths against a hand expansion
+    rng = np.random.RandomState(0)
+    x = rng.rand(62).astype(np.float32)
+    acc = [x[8 * a:8 * a + 8].copy() for a in range(4)]
+    for v in (4, 5, 6):
+        acc[0] = acc[0] + x[8 * v:8 * v + 8]
+    a0 = ((acc[0] + acc[1]) + acc[2]) + acc[3]
+    s = np.float32(0)
+    for k in range(56, 62):
+        s = np.float32(s + x[k])
+    for k in range(8):
+        s = np.float32(s + a0[k])
+    assert orc.aten_row_sum(x) == s
+
+
+@pytest.mark.parametrize("name", ["blender_p1", "blender_p6", "ndc_p30"])
+@pytest.mark.parametrize("nimp", [128, 64])
+def test_sample_pdf_merge_bit_exact(gold, name, nimp):
+    z, w = gold[f"spdf_{name}_z"], gold[f"spdf_{name}_w"]
+    zs, zm, sd = orc.sample_fine(z, w, nimp)
+    assert_bit_exact(zs, gold[f"spdf_{name}_n{nimp}_zs"], "z_samples")
+    assert_bit_exact(zm, gold[f"spdf_{name}_n{nimp}_zm"], "merged z_vals")
+    np.testing.assert_allclose(sd, gold[f"spdf_{name}_n{nimp}_std"], rtol=1e-5, atol=1e-7)
+    # the unit-level entry point agrees with the fused one
+    mids = (.5 * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    assert_bit_exact(orc.sample_pdf(mids, w[:, 1:-1], nimp), zs, "sample_pdf vs sample_fine")
+
+
+@pytest.mark.parametrize("name,wb", [("s64_white", True), ("s192", False), ("s7", True)])
+def test_raw2outputs(gold, name, wb):
+    g = lambda k: gold[f"r2o_{name}_{k}"]  # noqa: E731
+    rgb, disp, acc, w, depth = orc.raw2outputs(g("raw"), g("z"), g("d"), wb)
+    np.testing.assert_allclose(w, g("w"), atol=2e-7, rtol=2e-6)
+    np.testing.assert_allclose(rgb, g("rgb"), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(acc, g("acc"), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(depth, g("depth"), atol=1e-5, rtol=0)
+    ok = np.isfinite(g("disp"))
+    assert (np.isnan(disp) == np.isnan(g("disp"))).all()      # 0/0 rays stay NaN, like torch.max
+    np.testing.assert_allclose(disp[ok], g("disp")[ok], rtol=1e-5)
+    graw = orc.raw2outputs_bwd(g("raw"), g("z"), g("d"), g("grgb"), wb)
+    ref = g("graw")
+    np.testing.assert_allclose(graw, ref, atol=1e-6 + 1e-5 * np.abs(ref).max(), rtol=1e-4)
+
+
+def _net(seed, peaky=False, **kw):
+    return orc.Net(fx.make_nerf_state(seed, peaky=peaky, **kw), **{k: v for k, v in kw.items()})
+
+
+def test_nerf_forward(gold):
+    x = gold["mlp_x"]
+    # embedded input is itself reproduced by the oracle
+    e = np.concatenate([orc.embed(gold["mlp_pts"], 10), orc.embed(gold["mlp_dirs"], 4)], -1)
+    np.testing.assert_allclose(e, x, atol=2e-7, rtol=0)
+    for name, seed, peaky in (("default", 11, False), ("peaky", 12, True)):
+        net = orc.Net(fx.make_nerf_state(seed, peaky=peaky))
+        ref = gold[f"mlp_out_{name}"]
+        np.testing.assert_allclose(net.forward(x), ref, atol=1e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+    sd = fx.make_nerf_state(13, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=5, skips=(2,),
+                            use_viewdirs=False)
+    net = orc.Net(sd, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=5, skips=(2,), use_viewdirs=False)
+    np.testing.assert_allclose(net.forward(x[:, :63]), gold["mlp_out_noview"], atol=1e-5, rtol=0)
+
+
+RR_CASES = {
+    "blender": dict(white_bkgd=True, lindisp=False, N_importance=128),
+    "ndc": dict(white_bkgd=False, lindisp=False, N_importance=64),
+    "lindisp": dict(white_bkgd=False, lindisp=True, N_importance=128),
+}
+
+
+@pytest.mark.parametrize("name", list(RR_CASES))
+def test_render_rays(gold, name):
+    c = RR_CASES[name]
+    coarse = orc.Net(fx.make_nerf_state(21, peaky=True))
+    fine = orc.Net(fx.make_nerf_state(22, peaky=True))
+    ret = orc.render_rays(gold[f"rr_{name}_rays"], coarse, fine, 64, c["N_importance"], c["lindisp"],
+                          c["white_bkgd"], retraw=True)
+    for k in ("rgb0", "acc0", "disp0"):           # coarse pass: no resampling in between
+        np.testing.assert_allclose(ret[k], gold[f"rr_{name}_{k}"], atol=1e-5, rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(ret["weights0"], gold[f"rr_{name}_weights0"], atol=2e-6, rtol=1e-5)
+    # identical inputs -> bit-exact fine sample positions (the reference's coarse weights fed in)
+    rays = gold[f"rr_{name}_rays"]
+    _, zf, _ = orc.sample_fine(ret["z_vals0"], gold[f"rr_{name}_weights0"], c["N_importance"])
+    assert_bit_exact(zf, gold[f"rr_{name}_z_vals"], "fine z_vals on the reference's weights")
+    # identical sample positions -> fine network + compositing within 1e-4
+    raw = orc.run_network(orc.points(rays, zf), rays[:, -3:], fine)
+    ref_raw = gold[f"rr_{name}_raw"]
+    np.testing.assert_allclose(raw, ref_raw, atol=2e-5 * max(1, np.abs(ref_raw).max()), rtol=0)
+    rgb, disp, acc, _, _ = orc.raw2outputs(raw, zf, rays[:, 3:6], c["white_bkgd"])
+    np.testing.assert_allclose(rgb, gold[f"rr_{name}_rgb_map"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(acc, gold[f"rr_{name}_acc_map"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(disp, gold[f"rr_{name}_disp_map"], atol=1e-5, rtol=1e-5)
+    # end to end (the oracle's own coarse weights drive the resampler): see assert_mostly_close
+    for k in ("rgb_map", "acc_map", "disp_map", "z_std"):
+        assert_mostly_close(ret[k], gold[f"rr_{name}_{k}"], what=k, frac=0.9, hard=2e-2,
+                            rtol=1e-4 if k == "disp_map" else 0.0)
+
+
+def test_render_rays_noview_and_samefine(gold):
+    kw = dict(D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,), use_viewdirs=False)
+    small = orc.Net(fx.make_nerf_state(23, peaky=True, **kw), **kw)
+    q = lambda p, v, n: orc.run_network(p, None, n)  # noqa: E731
+    ret = orc.render_rays(gold["rr_noview_rays"], small, None, 64, 0, False, True, retraw=True, query=q)
+    assert "rgb0" not in ret
+    np.testing.assert_allclose(ret["rgb_map"], gold["rr_noview_rgb_map"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(ret["raw"], gold["rr_noview_raw"], atol=1e-4, rtol=1e-4)
+    ret = orc.render_rays(gold["rr_noview_rays"], small, None, 64, 32, False, False, query=q)
+    assert_mostly_close(ret["rgb_map"], gold["rr_samefine_rgb_map"], what="rgb")
+    assert_mostly_close(ret["z_std"], gold["rr_samefine_z_std"], what="z_std")
+
+
+def test_rays_and_render(gold):
+    H = W = 12
+    K = gold["render_blender_K"]
+    ro, rd = orc.get_rays(H, W, K, gold["render_blender_c2w"])
+    assert_bit_exact(ro, gold["render_blender_rays_o"], "rays_o")
+    np.testing.assert_allclose(rd, gold["render_blender_rays_d"], atol=1e-7, rtol=1e-6)
+    coarse = orc.Net(fx.make_nerf_state(21, peaky=True))
+    fine = orc.Net(fx.make_nerf_state(22, peaky=True))
+    rays = orc.build_rays(H, W, K, c2w=gold["render_blender_c2w"], near=2., far=6.)
+    ret = orc.render_rays(rays, coarse, fine, 64, 128, False, True)
+    assert_mostly_close(ret["rgb_map"].reshape(H, W, 3), gold["render_blender_rgb"], what="rgb")
+    assert_mostly_close(ret["acc_map"].reshape(H, W), gold["render_blender_acc"], what="acc")
+    np.testing.assert_allclose(ret["rgb0"].reshape(H, W, 3), gold["render_blender_rgb0"], atol=1e-5, rtol=0)
+    # NDC
+    H, W = 9, 12
+    K = gold["render_ndc_K"]
+    rays = orc.build_rays(H, W, K, c2w=gold["render_ndc_c2w"], ndc=True, near=0., far=1.)
+    np.testing.assert_allclose(rays[:, 0:3].reshape(H, W, 3), gold["render_ndc_rays_o"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(rays[:, 3:6].reshape(H, W, 3), gold["render_ndc_rays_d"], atol=1e-6, rtol=1e-5)
+    ret = orc.render_rays(rays, coarse, fine, 64, 64, False, False)
+    assert_mostly_close(ret["rgb_map"].reshape(H, W, 3), gold["render_ndc_rgb"], what="ndc rgb")
+    # static camera branch
+    H = W = 6
+    K, _ = fx.intrinsics(H, W)
+    rays = orc.build_rays(H, W, K, c2w=gold["render_blender_c2w"], near=2., far=6.,
+                          c2w_staticcam=gold["render_static_c2w"])
+    ret = orc.render_rays(rays, coarse, fine, 64, 128, False, True)
+    assert_mostly_close(ret["rgb_map"].reshape(H, W, 3), gold["render_static_rgb"], what="staticcam rgb")
+
+
+def grad_summary(g):
+    g = np.asarray(g, np.float64).reshape(-1)
+    idx = np.linspace(0, g.size - 1, min(256, g.size)).astype(np.int64)
+    return np.concatenate([[g.sum(), np.sqrt((g * g).sum())], g[idx]])
+
+
+def oracle_train_grads(ro, rd, target, coarse, fine, z_fine=None):
+    """loss and parameter gradients of train.py:226-243 on the oracle (perturb=0).  `z_fine`: use these
+    fine depths instead of resampling (removes the resampler's sensitivity from a gradient check)."""
+    n = ro.shape[0]
+    vd = (rd / np.linalg.norm(rd, axis=-1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([ro, rd, np.full((n, 1), 2, np.float32), np.full((n, 1), 6, np.float32), vd], -1)
+    ret = orc.render_rays(rays, coarse, fine, 64, 128, False, True, retraw=True)
+    if z_fine is not None:
+        raw = orc.run_network(orc.points(rays, z_fine), vd, fine)
+        rgb, _, _, _, _ = orc.raw2outputs(raw, z_fine, rd, True)
+        ret.update(z_vals=z_fine, rgb_map=rgb)
+    loss = np.mean((ret["rgb_map"].astype(np.float64) - target) ** 2) + \
+        np.mean((ret["rgb0"].astype(np.float64) - target) ** 2)
+    out = {}
+    for tag, net, rgbk, zk in (("coarse", coarse, "rgb0", "z_vals0"), ("fine", fine, "rgb_map", "z_vals")):
+        z = ret[zk]
+        pts = orc.points(rays, z)
+        e = np.concatenate([orc.embed(pts.reshape(-1, 3), 10),
+                            orc.embed(np.broadcast_to(vd[:, None], pts.shape).reshape(-1, 3), 4)], -1)
+        raw = net.forward(e).reshape(n, -1, 4)
+        g_rgb = (2.0 * (ret[rgbk].astype(np.float64) - target) / (n * 3)).astype(np.float32)
+        g_raw = orc.raw2outputs_bwd(raw, z, rd, g_rgb, True)
+        _, grads = net.forward_backward(e, g_raw.reshape(-1, 4))
+        out[tag] = grads
+    return loss, out, ret
+
+
+def test_train_step_grads(gold):
+    coarse = orc.Net(fx.make_nerf_state(21, peaky=True))
+    fine = orc.Net(fx.make_nerf_state(22, peaky=True))
+    loss, grads, ret = oracle_train_grads(gold["train_ro"], gold["train_rd"], gold["train_target"], coarse, fine,
+                                          z_fine=gold["train_z_vals"])
+    np.testing.assert_allclose(loss, gold["train_loss"][0], rtol=1e-5)
+    np.testing.assert_allclose(ret["rgb_map"], gold["train_rgb"], atol=1e-5, rtol=0)
+    for tag in ("coarse", "fine"):
+        for k, g in grads[tag].items():
+            ref = gold[f"train_grad_{tag}_{k}"]
+            got = grad_summary(g)
+            scale = max(ref[1], 1e-12)   # l2 norm of the reference gradient
+            assert abs(got[1] - ref[1]) <= 2e-3 * scale, (tag, k, got[1], ref[1])
+            np.testing.assert_allclose(got[2:], ref[2:], atol=2e-3 * scale / np.sqrt(max(1, g.size / 64)) + 1e-9,
+                                       rtol=5e-3, err_msg=f"{tag} {k}")
+
+
+# ---------------------------------------------------------------- D-NeRF
+def test_dnerf_embedders(gold_dnerf):
+    g = gold_dnerf
+    np.testing.assert_allclose(orc.embed(g["time_x"], 10), g["time_pe"], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(orc.embed(g["pe_noinp_x"], 4, include_input=False), g["pe_noinp"], atol=2e-7, rtol=0)
+
+
+def _dnerf_nets():
+    sd = fx.make_dnerf_state(31, peaky=True, dx_scale=3.0)
+    return orc.Net(sd, prefix="_occ."), orc.TimeNet(sd)
+
+
+def test_dnerf_forward(gold_dnerf):
+    g = gold_dnerf
+    occ, tn = _dnerf_nets()
+    pts, dirs = g["fwd_pts"], g["fwd_dirs"]
+    for name, tval in (("t0", 0.0), ("t05", 0.5)):
+        raw, dx = orc.run_network_dnerf(pts[:, None, :], dirs, np.full((pts.shape[0], 1), tval, np.float32), occ, tn)
+        np.testing.assert_allclose(dx[:, 0], g[f"fwd_{name}_dx"], atol=1e-5, rtol=0)
+        ref = g[f"fwd_{name}_out"]
+        np.testing.assert_allclose(raw[:, 0], ref, atol=3e-4 * max(1, np.abs(ref).max()), rtol=0)
+    e = np.concatenate([orc.embed(pts, 10), orc.embed(dirs, 4)], -1)
+    np.testing.assert_allclose(occ.forward(e), g["occ_out"], atol=1e-4, rtol=0)
+    assert not g["occ_zeros"].any()
+
+
+@pytest.mark.parametrize("name", ["t0", "t05", "tvar"])
+def test_dnerf_render_rays(gold_dnerf, name):
+    g = gold_dnerf
+    occ, tn = _dnerf_nets()
+    rays = g["rr_rays"]
+    times = g["rr_tvar_times"] if name == "tvar" else np.full((rays.shape[0], 1), {"t0": 0.0, "t05": 0.5}[name],
+                                                              np.float32)
+    dxs = []
+
+    def q(p, v, n):
+        raw, dx = orc.run_network_dnerf(p, v, times, occ, tn)
+        dxs.append(dx)
+        return raw
+    ret = orc.render_rays(rays, occ, None, 64, 128, False, True, query=q)
+    np.testing.assert_allclose(ret["rgb0"], g[f"rr_{name}_rgb0"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(dxs[0], g[f"rr_{name}_dx0"], atol=1e-5, rtol=0)
+    for k in ("rgb_map", "acc_map"):
+        assert_mostly_close(ret[k], g[f"rr_{name}_{k}"], what=k)
+    assert_mostly_close(dxs[1], g[f"rr_{name}_dx"], atol=2e-4, frac=0.995, hard=1.0, what="dx")
