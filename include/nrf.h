@@ -1,0 +1,117 @@
+/* nrf.h -- C ABI of libnrf.so, the MI355X (gfx950) implementation of the NeRF per-ray rendering path.
+ *
+ * The reference (duudual/NeRF, pure Python/PyTorch) has no FFI: the boundary it offers is the set of
+ * Python callables of positional_encoding.py / network.py / sampling.py / render.py.
+ * Each entry point below names the reference lines it replaces; the nerf_amd modules keep the reference's
+ * Python signatures and calls these through ctypes (see INTEGRATION.md for the binding a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *  - extern "C", plain C types.  Every tensor argument is a raw DEVICE pointer to a contiguous
+ *    row-major f32 buffer (tensor.data_ptr()) with explicit sizes.
+ *  - The caller allocates and owns every input, output and workspace buffer.  The library never
+ *    allocates, frees or retains device memory.
+ *  - Every call enqueues work on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *    returns without synchronising.
+ *  - Return value: 0 on success, otherwise a nrf_status; nrf_last_error_string() describes the last
+ *    failure on the calling thread.  No C++ exception crosses the boundary.
+ */
+#ifndef NRF_H_
+#define NRF_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRF_VERSION 100
+#define NRF_MAX_D 16
+
+typedef enum {
+    NRF_OK = 0,
+    NRF_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, ...) */
+    NRF_ERR_UNSUPPORTED = 2, /* shape outside what the kernels are built for */
+    NRF_ERR_LAUNCH = 3       /* HIP reported an error at launch */
+} nrf_status;
+
+int nrf_version(void);
+const char *nrf_last_error_string(void);
+
+/* ---- network description: the nn.Linear parameters of network.py:29-44 (weight [out,in], bias [out]) */
+typedef struct {
+    int32_t D, W, input_ch, input_ch_views, output_ch, use_viewdirs;
+    int32_t skips_mask;   /* bit i set <=> i in skips (network.py:52) */
+    int32_t reserved;
+    const float *pts_w[NRF_MAX_D];
+    const float *pts_b[NRF_MAX_D];
+    const float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+    const float *out_w, *out_b; /* output_linear (use_viewdirs == 0) */
+} nrf_net_t;
+
+/* how the query kernel obtains the network input */
+typedef struct {
+    int32_t mode;            /* 0: raw points/directions, positional encoding fused into the kernel;
+                                1: rows already embedded by the caller (NeRF.forward(x), network.py:46-47) */
+    int32_t multires;        /* L of get_embedder (positional_encoding.py:39-64); 3+6L == net.input_ch */
+    int32_t multires_views;  /* L for directions; 3+6L == net.input_ch_views (0 if !use_viewdirs)     */
+    int32_t multires_time;   /* D-NeRF time embedding L (vanilla_dynamic/positional_encoding.py:71-97) */
+} nrf_embed_t;
+
+/* K1  coarse depths  -- render.py:186-208 (linspace, near/far lerp or lindisp, optional stratified jitter)
+ * rays [N, ncol] = o(3) d(3) near far [viewdirs(3)]  (render.py:181-184); t_rand: NULL (perturb == 0) or
+ * [N, S] uniform randoms (render.py:200-206).  z_vals [N, S].  Bit-exact with the reference for perturb==0. */
+int nrf_sample_coarse(const float *rays, int64_t n_rays, int32_t ncol, int32_t n_samples, int32_t lindisp,
+                      const float *t_rand, float *z_vals, void *stream);
+
+/* pts = o + d * z -- render.py:210, :224.  pts [N, S, 3].  Bit-exact (separate multiply and add). */
+int nrf_points(const float *rays, int64_t n_rays, int32_t ncol, const float *z_vals, int32_t n_samples,
+               float *pts, void *stream);
+
+/* A1  Embedder.embed -- positional_encoding.py:5-36.  x [P, dims] -> out [P, dims*(include_input+2*num_freqs)] */
+int nrf_pe_fwd(const float *x, int64_t n_points, int32_t dims, int32_t num_freqs, float max_freq_log2,
+               int32_t log_sampling, int32_t include_input, float *out, void *stream);
+
+/* K2+K3 weights: nn.Linear layout -> the MFMA-fragment-ordered layout the query kernels stream.
+ * nrf_mlp_packed_floats returns the number of floats `packed` must hold (<= 0: unsupported shape). */
+int64_t nrf_mlp_packed_floats(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, float *packed, void *stream);
+
+/* K2+K3 network query, fused PE + MLP -- render.py:31-56 (run_network) + network.py:46-69 (NeRF.forward).
+ * mode 0: pts [P, 3]; viewdirs [P / pts_per_ray, 3] (one per ray, render.py:49) or NULL when !use_viewdirs.
+ * mode 1: pts is x [P, input_ch + input_ch_views] (already embedded), viewdirs ignored.
+ * raw [P, 4] (use_viewdirs) or [P, output_ch].  `net` supplies the dimensions only (pointers unused);
+ * `packed` must have been produced by nrf_mlp_pack_weights with the same net/emb. */
+int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                  const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
+
+/* K4  raw2outputs -- render.py:82-131.  raw [N,S,4], z_vals [N,S], rays_d rows of `d_stride` floats
+ * (pass rays+3 with d_stride = ncol to read directions out of the ray matrix), noise NULL or [N,S]
+ * (already multiplied by raw_noise_std).  Outputs rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]. */
+int nrf_composite_fwd(const float *raw, const float *z_vals, const float *rays_d, int32_t d_stride,
+                      int64_t n_rays, int32_t n_samples, const float *noise, int32_t white_bkgd, float *rgb_map,
+                      float *disp_map, float *acc_map, float *weights, float *depth_map, void *stream);
+
+/* K4b backward of raw2outputs w.r.t. raw -- autograd of render.py:100-129.  g_rgb [N,3] is required;
+ * g_disp, g_acc, g_depth [N] and g_weights [N,S] may be NULL (train.py:232-239 only uses rgb).  g_raw [N,S,4]. */
+int nrf_composite_bwd(const float *raw, const float *z_vals, const float *rays_d, int32_t d_stride,
+                      int64_t n_rays, int32_t n_samples, const float *noise, int32_t white_bkgd,
+                      const float *g_rgb, const float *g_acc, const float *g_depth, const float *g_weights,
+                      float *g_raw, void *stream);
+
+/* K5  hierarchical resampling -- sampling.py:5-60 on weights[...,1:-1] and mid-points, then
+ * sort(cat(z_vals, z_samples)) and std(z_samples) -- render.py:219-224, :238.
+ * z_vals [N,S], weights [N,S] (full coarse rows); u NULL (det, perturb == 0) or [N, n_importance].
+ * z_samples [N, n_importance] (may be NULL), z_merged [N, S+n_importance], z_std [N] (may be NULL).
+ * Bit-exact with the reference CPU path on identical inputs. */
+int nrf_sample_fine(const float *z_vals, const float *weights, int64_t n_rays, int32_t n_samples,
+                    int32_t n_importance, const float *u, float *z_samples, float *z_merged, float *z_std,
+                    void *stream);
+
+/* sample_pdf alone -- sampling.py:5-60.  bins [N, nb], weights [N, nb-1] -> samples [N, n_samples]. */
+int nrf_sample_pdf(const float *bins, const float *weights, int64_t n_rows, int32_t n_bins, int32_t n_samples,
+                   const float *u, float *samples, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRF_H_ */

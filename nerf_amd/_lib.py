@@ -1,0 +1,71 @@
+"""ctypes binding of libnrf.so (include/nrf.h).  There is no CPU fallback: if the HIP library is
+missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnrf.so")
+MAX_D = 16
+f32p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class NrfNet(C.Structure):
+    """nrf_net_t"""
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("input_ch", C.c_int32), ("input_ch_views", C.c_int32),
+                ("output_ch", C.c_int32), ("use_viewdirs", C.c_int32), ("skips_mask", C.c_int32),
+                ("reserved", C.c_int32),
+                ("pts_w", vp * MAX_D), ("pts_b", vp * MAX_D),
+                ("views_w", vp), ("views_b", vp), ("feature_w", vp), ("feature_b", vp),
+                ("alpha_w", vp), ("alpha_b", vp), ("rgb_w", vp), ("rgb_b", vp),
+                ("out_w", vp), ("out_b", vp)]
+
+
+class NrfEmbed(C.Structure):
+    """nrf_embed_t"""
+    _fields_ = [("mode", C.c_int32), ("multires", C.c_int32), ("multires_views", C.c_int32),
+                ("multires_time", C.c_int32)]
+
+
+_lib = None
+
+_SIGS = {
+    "nrf_version": (C.c_int, []),
+    "nrf_last_error_string": (C.c_char_p, []),
+    "nrf_sample_coarse": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
+    "nrf_points": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp]),
+    "nrf_pe_fwd": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, vp, vp]),
+    "nrf_mlp_packed_floats": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
+    "nrf_mlp_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
+    "nrf_query_fwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),
+    "nrf_composite_fwd": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp,
+                                    vp]),
+    "nrf_composite_bwd": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp,
+                                    vp]),
+    "nrf_sample_fine": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]),
+    "nrf_sample_pdf": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C nerf_amd/csrc` "
+                               "(or __graft_entry__.build()); nerf_amd has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().nrf_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")

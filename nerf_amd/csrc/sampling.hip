@@ -1,0 +1,297 @@
+// Sampling kernels (K1 coarse sampler, K5 hierarchical resampler) for gfx950.
+//
+// Sample positions must be BIT-EXACT with the reference's CPU path.  HIP's
+// __fmul_rn/__fadd_rn are plain * and + to the compiler, so a*b+c would still be contracted into an
+// FMA under hipcc's default -ffp-contract=fast: this file is compiled with -ffp-contract=off (Makefile)
+// AND carries the pragma below; the only fused operation is the explicit __fmaf_rn of linspace.
+//
+// K1: one thread per (ray, sample) element; coalesced [N,S] stores.           HBM-bound, tiny.
+// K5: one wavefront per ray.  The ray's bins / weights / cdf live in LDS; the 62-term weight sum is
+//     evaluated in ATen's fixed order, the cdf is an f64 running sum (exact, see below), each lane
+//     inverts the cdf for its samples by binary search, and the merged depth list is produced by
+//     rank-merge (or a bitonic sort when the new samples are not monotone).  Loads and stores are
+//     whole contiguous rows per wave (256..768 B), i.e. coalesced.
+#include "nrf_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// torch.linspace(0, 1, n)[i] on CPU: step = rn(1/(n-1)); two-sided, one fused rounding per element.
+__device__ __forceinline__ float linspace01(int i, int n, float step) {
+    if (n == 1) return 0.0f;
+    return (i < n / 2) ? __fmaf_rn(step, (float)i, 0.0f) : __fmaf_rn(-step, (float)(n - 1 - i), 1.0f);
+}
+
+__device__ __forceinline__ float coarse_z(float near, float far, int i, int S, float step, bool lindisp) {
+    float t = linspace01(i, S, step);
+    float omt = __fsub_rn(1.0f, t);
+    if (!lindisp) return __fadd_rn(__fmul_rn(near, omt), __fmul_rn(far, t));                // render.py:188
+    float a = __fmul_rn(__fdiv_rn(1.0f, near), omt), b = __fmul_rn(__fdiv_rn(1.0f, far), t);
+    return __fdiv_rn(1.0f, __fadd_rn(a, b));                                                // render.py:190
+}
+
+__global__ void __launch_bounds__(256) sample_coarse_kernel(const float *__restrict__ rays, int64_t total, int ncol,
+                                                            int S, int lindisp,
+                                                            const float *__restrict__ t_rand,
+                                                            float *__restrict__ z_vals) {
+    const float step = (S > 1) ? __fdiv_rn(1.0f, (float)(S - 1)) : 0.0f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e / S;
+        int i = (int)(e - r * S);
+        float near = rays[r * ncol + 6], far = rays[r * ncol + 7];
+        float z = (S > 1) ? coarse_z(near, far, i, S, step, lindisp) : near;
+        if (t_rand) {  // stratified jitter, render.py:194-208
+            float zl = (i > 0) ? coarse_z(near, far, i - 1, S, step, lindisp) : z;
+            float zu = (i + 1 < S) ? coarse_z(near, far, i + 1, S, step, lindisp) : z;
+            float upper = (i + 1 < S) ? __fmul_rn(0.5f, __fadd_rn(zu, z)) : z;
+            float lower = (i > 0) ? __fmul_rn(0.5f, __fadd_rn(z, zl)) : z;
+            z = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[e]));
+        }
+        z_vals[e] = z;
+    }
+}
+
+__global__ void __launch_bounds__(256) points_kernel(const float *__restrict__ rays, int64_t total, int ncol, int S,
+                                                     const float *__restrict__ z_vals, float *__restrict__ pts) {
+    // one thread per output float: pts[(r*S+i)*3+c] = o[c] + d[c]*z  (render.py:210: separate mul and add)
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s = e / 3;
+        int c = (int)(e - s * 3);
+        int64_t r = s / S;
+        pts[e] = __fadd_rn(rays[r * ncol + c], __fmul_rn(rays[r * ncol + 3 + c], z_vals[s]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxBins = 256;     // S-1 <= 256
+constexpr int kMaxMerged = 1024;  // S + n_importance <= 1024
+
+struct FineSmem {
+    float bins[kMaxBins];
+    float cdf[kMaxBins];
+    float w[kMaxBins];
+    float zs[kMaxMerged];      // new samples
+    float merged[kMaxMerged];  // sort buffer / staging
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per ray.  mode_fine: bins/weights are derived from (z_vals, full weights) as render.py:219-220
+// does; otherwise `zin` IS bins [nb] and `win` IS weights [nb-1] (plain sample_pdf).
+__global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restrict__ zin,
+                                                          const float *__restrict__ win, int64_t N, int S, int ns,
+                                                          int mode_fine, const float *__restrict__ u_in,
+                                                          float *__restrict__ z_samples,
+                                                          float *__restrict__ z_merged, float *__restrict__ z_std) {
+    __shared__ FineSmem sm[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    FineSmem &m = sm[wave];
+    const int nb = mode_fine ? S - 1 : S;  // number of bins
+    const int nw = nb - 1;                 // number of pdf weights
+    const int zrow = mode_fine ? S : nb;   // row length of zin
+    const int wrow = mode_fine ? S : nw;   // row length of win
+    const float ustep = (ns > 1) ? __fdiv_rn(1.0f, (float)(ns - 1)) : 0.0f;
+    const int total = S + ns;
+
+    for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < N; r0 += (int64_t)gridDim.x * 4) {
+        const int64_t r = r0 + wave;
+        const bool live = r < N;  // wave-uniform
+        if (live) {
+            const float *z = zin + r * zrow;
+            const float *wt = win + r * wrow;
+            for (int i = lane; i < nb; i += 64)
+                m.bins[i] = mode_fine ? __fmul_rn(0.5f, __fadd_rn(z[i + 1], z[i])) : z[i];   // render.py:219
+            for (int i = lane; i < nw; i += 64)
+                m.w[i] = __fadd_rn(mode_fine ? wt[i + 1] : wt[i], 1e-5f);                    // sampling.py:19
+        }
+        __syncthreads();
+        float s = 0.0f;
+        if (live) {
+            // sampling.py:20 torch.sum(weights, -1): ATen vectorized_inner_sum order (8 lanes x ILP 4).
+            // Lanes 0..7 each own one vector lane k; the final fold over k is done by every lane.
+            const int nv = nw >> 3, rounds = nv >> 2;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const int k = lane & 7;
+            for (int i = 0; i < rounds; ++i) {
+                a0 = __fadd_rn(a0, m.w[(i * 4 + 0) * 8 + k]);
+                a1 = __fadd_rn(a1, m.w[(i * 4 + 1) * 8 + k]);
+                a2 = __fadd_rn(a2, m.w[(i * 4 + 2) * 8 + k]);
+                a3 = __fadd_rn(a3, m.w[(i * 4 + 3) * 8 + k]);
+            }
+            for (int v = rounds * 4; v < nv; ++v) a0 = __fadd_rn(a0, m.w[v * 8 + k]);
+            a0 = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+            for (int i = nv * 8; i < nw; ++i) s = __fadd_rn(s, m.w[i]);
+            for (int kk = 0; kk < 8; ++kk) s = __fadd_rn(s, __shfl(a0, kk));
+            // sampling.py:20-22 pdf = w / s; cdf = [0, cumsum(pdf)].  ATen's CPU cumsum keeps an f64 running
+            // sum and rounds each prefix to f32.  Each pdf is an f32 in [~1e-5/s, 1], so every f64 partial
+            // sum is exact (<= 47 significant bits) and a parallel prefix gives the sequential result.
+            double carry = 0.0;
+            for (int base = 0; base < nw; base += 64) {
+                int i = base + lane;
+                double p = (i < nw) ? (double)__fdiv_rn(m.w[i], s) : 0.0;
+                for (int o = 1; o < 64; o <<= 1) {
+                    double q = __shfl_up(p, o);
+                    if (lane >= o) p += q;
+                }
+                p += carry;
+                if (i < nw) m.cdf[i + 1] = (float)p;
+                carry = __shfl(p, 63);
+            }
+            if (lane == 0) m.cdf[0] = 0.0f;
+        }
+        __syncthreads();
+        bool sorted_ok = true;
+        double sum1 = 0.0;
+        if (live) {
+            float prev_last = -INFINITY;
+            for (int base = 0; base < ns; base += 64) {
+                int j = base + lane;
+                float out = INFINITY;
+                if (j < ns) {
+                    float u = u_in ? u_in[r * ns + j] : linspace01(j, ns, ustep);            // sampling.py:25-29
+                    int lo = 0, hi = nb;  // searchsorted(cdf, u, right=True): first idx with cdf[idx] > u
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (m.cdf[mid] > u) hi = mid; else lo = mid + 1;
+                    }
+                    int below = max(lo - 1, 0), above = min(lo, nb - 1);                     // sampling.py:45-46
+                    float c0 = m.cdf[below], c1 = m.cdf[above], b0 = m.bins[below], b1 = m.bins[above];
+                    float denom = __fsub_rn(c1, c0);
+                    if (denom < 1e-5f) denom = 1.0f;                                         // sampling.py:56
+                    float t = __fdiv_rn(__fsub_rn(u, c0), denom);
+                    out = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));                    // sampling.py:58
+                    m.zs[j] = out;
+                    if (z_samples) z_samples[r * ns + j] = out;
+                    sum1 += (double)out;
+                }
+                // monotonicity check (rank-merge below needs a sorted list)
+                float left = __shfl_up(out, 1);
+                if (lane == 0) left = prev_last;
+                if (j < ns && out < left) sorted_ok = false;
+                prev_last = __shfl(out, 63);
+            }
+            sorted_ok = __all(sorted_ok);
+        }
+        __syncthreads();
+        if (live && z_std) {  // render.py:238 torch.std(z_samples, unbiased=False); tolerance-level
+            double mean = wave_sum_f64(sum1) / (double)ns;
+            double v = 0.0;
+            for (int j = lane; j < ns; j += 64) {
+                double d = (double)m.zs[j] - mean;
+                v += d * d;
+            }
+            v = wave_sum_f64(v);
+            if (lane == 0) z_std[r] = (float)sqrt(v / (double)ns);
+        }
+        if (mode_fine && z_merged) {  // render.py:223 sort(cat([z_vals, z_samples]))  (values only)
+            const float *z = zin + (live ? r : 0) * zrow;
+            bool zsorted = true;
+            if (live) {
+                for (int i = lane; i + 1 < S; i += 64)
+                    if (z[i + 1] < z[i]) zsorted = false;
+                zsorted = __all(zsorted);
+            }
+            const bool fast = live && sorted_ok && zsorted;  // wave-uniform
+            if (fast) {
+                // rank-merge of two sorted lists: rank(z[i]) = i + #{zs < z[i]}, rank(zs[j]) = j + #{z <= zs[j]}
+                float *out = z_merged + r * total;
+                for (int i = lane; i < S; i += 64) {
+                    float v = z[i];
+                    int lo = 0, hi = ns;
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if (m.zs[mid] < v) lo = mid + 1; else hi = mid; }
+                    out[i + lo] = v;
+                }
+                for (int j = lane; j < ns; j += 64) {
+                    float v = m.zs[j];
+                    int lo = 0, hi = S;
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if (z[mid] <= v) lo = mid + 1; else hi = mid; }
+                    out[j + lo] = v;
+                }
+            }
+            // slow path (any wave of the block may need it -> block-uniform control flow for the barriers)
+            int need_sort = __syncthreads_or(live && !fast);
+            if (need_sort) {
+                int T2 = 1;
+                while (T2 < total) T2 <<= 1;
+                if (live && !fast) {
+                    for (int i = lane; i < T2; i += 64)
+                        m.merged[i] = (i < S) ? z[i] : (i < total ? m.zs[i - S] : INFINITY);
+                }
+                __syncthreads();
+                for (int k = 2; k <= T2; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        if (live && !fast)
+                            for (int i = lane; i < T2; i += 64) {
+                                int p = i ^ j;
+                                if (p > i) {
+                                    float a = m.merged[i], b = m.merged[p];
+                                    bool up = (i & k) == 0;
+                                    if ((a > b) == up) { m.merged[i] = b; m.merged[p] = a; }
+                                }
+                            }
+                        __syncthreads();
+                    }
+                if (live && !fast)
+                    for (int i = lane; i < total; i += 64) z_merged[r * total + i] = m.merged[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int nrf_sample_coarse(const float *rays, int64_t n_rays, int32_t ncol, int32_t n_samples,
+                                 int32_t lindisp, const float *t_rand, float *z_vals, void *stream) {
+    NRF_REQUIRE(rays && z_vals, "nrf_sample_coarse: null pointer");
+    NRF_REQUIRE(n_rays >= 0 && ncol >= 8 && n_samples >= 1, "nrf_sample_coarse: bad sizes (n_rays=%lld ncol=%d S=%d)",
+                (long long)n_rays, ncol, n_samples);
+    if (n_rays == 0) return NRF_OK;
+    int64_t total = n_rays * n_samples;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3(nrf::grid_for(total, 256)), dim3(256), 0, nrf::as_stream(stream),
+                       rays, total, ncol, n_samples, lindisp, t_rand, z_vals);
+    return nrf::check_launch("nrf_sample_coarse");
+}
+
+extern "C" int nrf_points(const float *rays, int64_t n_rays, int32_t ncol, const float *z_vals, int32_t n_samples,
+                          float *pts, void *stream) {
+    NRF_REQUIRE(rays && z_vals && pts, "nrf_points: null pointer");
+    NRF_REQUIRE(n_rays >= 0 && ncol >= 6 && n_samples >= 1, "nrf_points: bad sizes");
+    if (n_rays == 0) return NRF_OK;
+    int64_t total = n_rays * n_samples * 3;
+    hipLaunchKernelGGL(points_kernel, dim3(nrf::grid_for(total, 256)), dim3(256), 0, nrf::as_stream(stream), rays,
+                       total, ncol, n_samples, z_vals, pts);
+    return nrf::check_launch("nrf_points");
+}
+
+extern "C" int nrf_sample_fine(const float *z_vals, const float *weights, int64_t n_rays, int32_t n_samples,
+                               int32_t n_importance, const float *u, float *z_samples, float *z_merged,
+                               float *z_std, void *stream) {
+    NRF_REQUIRE(z_vals && weights && z_merged, "nrf_sample_fine: null pointer");
+    NRF_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1, "nrf_sample_fine: bad sizes");
+    if (n_samples - 1 > kMaxBins || n_samples + n_importance > kMaxMerged)
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_fine: N_samples-1 <= %d and N_samples+N_importance <= %d",
+                         kMaxBins, kMaxMerged);
+    if (n_rays == 0) return NRF_OK;
+    hipLaunchKernelGGL(sample_fine_kernel, dim3(nrf::grid_for(n_rays, 4)), dim3(256), 0, nrf::as_stream(stream),
+                       z_vals, weights, n_rays, n_samples, n_importance, 1, u, z_samples, z_merged, z_std);
+    return nrf::check_launch("nrf_sample_fine");
+}
+
+extern "C" int nrf_sample_pdf(const float *bins, const float *weights, int64_t n_rows, int32_t n_bins,
+                              int32_t n_samples, const float *u, float *samples, void *stream) {
+    NRF_REQUIRE(bins && weights && samples, "nrf_sample_pdf: null pointer");
+    NRF_REQUIRE(n_rows >= 0 && n_bins >= 2 && n_samples >= 1, "nrf_sample_pdf: bad sizes");
+    if (n_bins > kMaxBins || n_samples > kMaxMerged)
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_pdf: n_bins <= %d, n_samples <= %d", kMaxBins, kMaxMerged);
+    if (n_rows == 0) return NRF_OK;
+    hipLaunchKernelGGL(sample_fine_kernel, dim3(nrf::grid_for(n_rows, 4)), dim3(256), 0, nrf::as_stream(stream),
+                       bins, weights, n_rows, n_bins, n_samples, 0, u, samples, (float *)nullptr, (float *)nullptr);
+    return nrf::check_launch("nrf_sample_pdf");
+}

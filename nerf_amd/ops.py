@@ -1,0 +1,198 @@
+"""Tensor-level wrappers over the C ABI: torch is used for device memory and streams only.
+
+Every function takes contiguous float32 CUDA(HIP) tensors, allocates its outputs with torch.empty and
+enqueues one or more HIP kernels on torch's current stream.  No CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NrfEmbed, NrfNet, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: nerf_amd kernels need a GPU tensor (got device {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---------------------------------------------------------------- sampling
+def sample_coarse(rays, n_samples, lindisp=False, t_rand=None):
+    """render.py:186-208 -> z_vals [N, S]."""
+    rays = _f32(rays, "rays")
+    N, ncol = rays.shape
+    z = torch.empty((N, n_samples), device=rays.device, dtype=torch.float32)
+    if t_rand is not None:
+        t_rand = _f32(t_rand, "t_rand")
+        assert t_rand.shape == (N, n_samples)
+    check(_lib.lib().nrf_sample_coarse(_ptr(rays), N, ncol, n_samples, int(bool(lindisp)), _ptr(t_rand), _ptr(z),
+                                       _stream()), "nrf_sample_coarse")
+    return z
+
+
+def points(rays, z_vals):
+    """render.py:210 / :224 -> pts [N, S, 3]."""
+    rays, z_vals = _f32(rays, "rays"), _f32(z_vals, "z_vals")
+    N, S = z_vals.shape
+    pts = torch.empty((N, S, 3), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nrf_points(_ptr(rays), N, rays.shape[1], _ptr(z_vals), S, _ptr(pts), _stream()), "nrf_points")
+    return pts
+
+
+def sample_fine(z_vals, weights, n_importance, u=None, want_samples=True):
+    """render.py:219-224, :238 -> (z_samples, z_merged, z_std)."""
+    z_vals, weights = _f32(z_vals, "z_vals"), _f32(weights, "weights")
+    N, S = z_vals.shape
+    assert weights.shape == (N, S)
+    dev = z_vals.device
+    zs = torch.empty((N, n_importance), device=dev, dtype=torch.float32) if want_samples else None
+    zm = torch.empty((N, S + n_importance), device=dev, dtype=torch.float32)
+    sd = torch.empty((N,), device=dev, dtype=torch.float32)
+    if u is not None:
+        u = _f32(u, "u")
+        assert u.shape == (N, n_importance)
+    check(_lib.lib().nrf_sample_fine(_ptr(z_vals), _ptr(weights), N, S, n_importance, _ptr(u), _ptr(zs), _ptr(zm),
+                                     _ptr(sd), _stream()), "nrf_sample_fine")
+    return zs, zm, sd
+
+
+def sample_pdf(bins, weights, n_samples, u=None):
+    """sampling.py:5-60."""
+    bins, weights = _f32(bins, "bins"), _f32(weights, "weights")
+    lead = bins.shape[:-1]
+    nb = bins.shape[-1]
+    b2, w2 = bins.reshape(-1, nb), weights.reshape(-1, nb - 1)
+    out = torch.empty((b2.shape[0], n_samples), device=bins.device, dtype=torch.float32)
+    if u is not None:
+        u = _f32(u, "u").reshape(-1, n_samples)
+    check(_lib.lib().nrf_sample_pdf(_ptr(b2), _ptr(w2), b2.shape[0], nb, n_samples, _ptr(u), _ptr(out), _stream()),
+          "nrf_sample_pdf")
+    return out.reshape(*lead, n_samples)
+
+
+# ---------------------------------------------------------------- positional encoding
+def pe_fwd(x, num_freqs, max_freq_log2, log_sampling=True, include_input=True):
+    x = _f32(x, "x")
+    dims = x.shape[-1]
+    flat = x.reshape(-1, dims)
+    od = dims * ((1 if include_input else 0) + 2 * num_freqs)
+    out = torch.empty((flat.shape[0], od), device=x.device, dtype=torch.float32)
+    check(_lib.lib().nrf_pe_fwd(_ptr(flat), flat.shape[0], dims, num_freqs, float(max_freq_log2), int(log_sampling),
+                                int(include_input), _ptr(out), _stream()), "nrf_pe_fwd")
+    return out.reshape(*x.shape[:-1], od)
+
+
+# ---------------------------------------------------------------- compositing
+def _dirs(rays_d):
+    """rays_d may be a strided view into the [N, ncol] ray matrix; pass (base pointer, row stride)."""
+    if rays_d.dtype == torch.float32 and rays_d.is_cuda and rays_d.dim() == 2 and rays_d.shape[1] == 3 \
+            and rays_d.stride(1) == 1 and rays_d.stride(0) >= 3:
+        return rays_d, rays_d.stride(0)
+    d = _f32(rays_d, "rays_d")
+    return d, 3
+
+
+def composite_fwd(raw, z_vals, rays_d, noise=None, white_bkgd=False):
+    raw, z_vals = _f32(raw, "raw"), _f32(z_vals, "z_vals")
+    N, S = z_vals.shape
+    assert raw.shape == (N, S, 4), f"raw must be [N,S,4], got {tuple(raw.shape)}"
+    d, ds = _dirs(rays_d)
+    assert d.shape[0] == N
+    dev = raw.device
+    rgb = torch.empty((N, 3), device=dev, dtype=torch.float32)
+    disp, acc, depth = (torch.empty((N,), device=dev, dtype=torch.float32) for _ in range(3))
+    w = torch.empty((N, S), device=dev, dtype=torch.float32)
+    if noise is not None:
+        noise = _f32(noise, "noise")
+    check(_lib.lib().nrf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(d), ds, N, S, _ptr(noise), int(bool(white_bkgd)),
+                                       _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(w), _ptr(depth), _stream()),
+          "nrf_composite_fwd")
+    return rgb, disp, acc, w, depth
+
+
+def composite_bwd(raw, z_vals, rays_d, g_rgb, g_acc=None, g_depth=None, g_weights=None, noise=None,
+                  white_bkgd=False):
+    raw, z_vals, g_rgb = _f32(raw, "raw"), _f32(z_vals, "z_vals"), _f32(g_rgb, "g_rgb")
+    N, S = z_vals.shape
+    d, ds = _dirs(rays_d)
+    g_raw = torch.empty((N, S, 4), device=raw.device, dtype=torch.float32)
+    opt = [None if t is None else _f32(t, "grad") for t in (g_acc, g_depth, g_weights, noise)]
+    check(_lib.lib().nrf_composite_bwd(_ptr(raw), _ptr(z_vals), _ptr(d), ds, N, S, _ptr(opt[3]),
+                                       int(bool(white_bkgd)), _ptr(g_rgb), _ptr(opt[0]), _ptr(opt[1]), _ptr(opt[2]),
+                                       _ptr(g_raw), _stream()), "nrf_composite_bwd")
+    return g_raw
+
+
+# ---------------------------------------------------------------- network query
+class PackedNet:
+    """MFMA-ordered copy of a NeRF module's nn.Linear parameters (network.py:29-44).
+
+    The nn.Linear parameters stay the source of truth (checkpoints, Adam); `refresh()` repacks when
+    any parameter's version counter moved (after optimizer.step() or load_state_dict())."""
+
+    def __init__(self, params, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, mode=0,
+                 multires=0, multires_views=0, multires_time=0):
+        self.params = params  # dict name -> tensor with reference state_dict key names
+        self.net = NrfNet()
+        n = self.net
+        n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch = D, W, input_ch, input_ch_views, output_ch
+        n.use_viewdirs = int(bool(use_viewdirs))
+        n.skips_mask = sum(1 << int(s) for s in skips)
+        self.emb = NrfEmbed(mode, multires, multires_views, multires_time)
+        self.n_floats = _lib.lib().nrf_mlp_packed_floats(C.byref(n), C.byref(self.emb))
+        if self.n_floats <= 0:
+            raise RuntimeError("nrf_mlp_packed_floats: " + _lib.lib().nrf_last_error_string().decode())
+        self.packed = None
+        self._versions = None
+        self.out_ch = 4 if use_viewdirs else output_ch
+
+    def _fill_pointers(self):
+        n, g = self.net, lambda k: C.c_void_p(self._p[k].data_ptr())  # noqa: E731
+        self._p = {k: _f32(v.detach(), k) for k, v in self.params.items()}
+        for i in range(n.D):
+            n.pts_w[i] = g(f"pts_linears.{i}.weight")
+            n.pts_b[i] = g(f"pts_linears.{i}.bias")
+        if n.use_viewdirs:
+            n.views_w, n.views_b = g("views_linears.0.weight"), g("views_linears.0.bias")
+            n.feature_w, n.feature_b = g("feature_linear.weight"), g("feature_linear.bias")
+            n.alpha_w, n.alpha_b = g("alpha_linear.weight"), g("alpha_linear.bias")
+            n.rgb_w, n.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
+        else:
+            n.out_w, n.out_b = g("output_linear.weight"), g("output_linear.bias")
+
+    def refresh(self):
+        vers = tuple((v.data_ptr(), v._version) for v in self.params.values())
+        if self.packed is not None and vers == self._versions:
+            return
+        self._fill_pointers()
+        dev = next(iter(self._p.values())).device
+        if self.packed is None or self.packed.device != dev:
+            self.packed = torch.empty((self.n_floats,), device=dev, dtype=torch.float32)
+        check(_lib.lib().nrf_mlp_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()),
+              "nrf_mlp_pack_weights")
+        self._versions = vers
+
+    def query(self, pts, viewdirs=None, pts_per_ray=1):
+        """mode 0: pts [P,3] (+ viewdirs [P/pts_per_ray,3]); mode 1: pts = embedded rows [P, in+views]."""
+        self.refresh()
+        pts = _f32(pts, "pts")
+        P = pts.shape[0]
+        raw = torch.empty((P, self.out_ch), device=pts.device, dtype=torch.float32)
+        if viewdirs is not None:
+            viewdirs = _f32(viewdirs, "viewdirs")
+        check(_lib.lib().nrf_query_fwd(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                       _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _stream()), "nrf_query_fwd")
+        return raw
