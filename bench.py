@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/sec of the NeRF per-ray rendering path at 64 coarse + 128 fine samples per ray.
+
+    python bench.py --gpus N --steps K --warmup W [--workload render|train] [--size 800]
+
+A step = one full render of a synthetic 800x800 view (BASELINE.json configs[1]: D=8/W=256 coarse+fine
+nets, multires 10/4, view directions, white background, near/far 2/6, chunk 32768, perturb=0) through
+nerf_amd.render.render().  Weights are seeded random-init (+ the "peaky" head scaling of SURVEY 8c),
+poses come from the spherical-pose formula: data is synthetic, there is no dataset offline.
+With N > 1 (launched by torch.distributed.run) the image's rows are sharded over the ranks and one
+gather returns (rgb, disp, acc) to rank 0: strong scaling of one image.
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the fused PE+MLP query,
+MFMA-bound) from HIP-event durations of every query launch inside the timed region; `cpu_baseline` is
+the C oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded ray sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_POINT = 2 * (63 * 256 + 6 * 256 * 256 + 319 * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3)  # 1 186 816
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="render", choices=["render", "train"])
+    ap.add_argument("--size", type=int, default=800, help="image side (render workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def build_nets(torch, device):
+    import nerf_fixtures as fx
+    from nerf_amd.network import NeRF
+    nets = []
+    for seed in (21, 22):
+        net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        sd = fx.make_nerf_state(seed, peaky=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(net.to(device))
+    return nets
+
+
+class QueryTimer:
+    """Brackets every fused-query launch with HIP events (on torch's current stream, the one the C ABI
+    launches on) while enabled; durations are read after the timed region."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.enabled = False
+        self.events = []
+
+    def install(self):
+        from nerf_amd import ops
+        orig, timer, torch = ops.PackedNet.query, self, self.torch
+
+        def timed(pk, pts, viewdirs=None, pts_per_ray=1):
+            if not timer.enabled:
+                return orig(pk, pts, viewdirs, pts_per_ray)
+            pk.refresh()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(pk, pts, viewdirs, pts_per_ray)
+            e1.record()
+            timer.events.append((e0, e1, pts.shape[0]))
+            return out
+        ops.PackedNet.query = timed
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
+        pts = sum(n for _, _, n in self.events)
+        return ms, pts, len(self.events)
+
+
+def cpu_baseline(n_rays):
+    """The oracle (C restatement of the reference's CPU path) on a bounded sample of the same workload."""
+    import nerf_fixtures as fx
+    from oracle import oracle as orc
+    coarse = orc.Net(fx.make_nerf_state(21, peaky=True))
+    fine = orc.Net(fx.make_nerf_state(22, peaky=True))
+    H = W = 800
+    K, _ = fx.intrinsics(H, W)
+    rng = np.random.RandomState(0)
+    pix = np.stack([rng.randint(0, H, n_rays), rng.randint(0, W, n_rays)], -1)
+    ro, rd = fx.pinhole_rays_np(H, W, K, fx.pose_spherical(30.0, -30.0, 4.0), pix)
+    vd = (rd / np.linalg.norm(rd, axis=-1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([ro, rd, np.full((n_rays, 1), 2, np.float32), np.full((n_rays, 1), 6, np.float32), vd], -1)
+    orc.render_rays(rays[:64], coarse, fine, 64, 128, False, True)  # warm-up (thread pool, page-in)
+    t0 = time.time()
+    orc.render_rays(rays, coarse, fine, 64, 128, False, True)
+    dt = time.time() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n_rays} random rays of the 800x800 view, 64+128 samples, oracle/liborc.so (OpenMP), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    import nerf_fixtures as fx
+    from nerf_amd import parallel
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.rays import get_rays
+    from nerf_amd.render import render, run_network
+
+    if args.workload == "train":
+        from bench_train import run_train
+        return run_train(args, torch, dist, world, rank, device)
+
+    coarse, fine = build_nets(torch, device)
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
+              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
+              raw_noise_std=0., ndc=False, lindisp=False)
+    H = W = args.size
+    K, _ = fx.intrinsics(H, W)
+    timer = QueryTimer(torch)
+    timer.install()
+
+    def step(i):
+        c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
+        with torch.no_grad():
+            if world == 1:
+                rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=2., far=6., **kw)
+                return rgb
+            ro_full, rd_full = get_rays(H, W, K, c2w)
+
+            def rows(row0, nrows):
+                rays = torch.stack([ro_full[row0:row0 + nrows].reshape(-1, 3), rd_full[row0:row0 + nrows].reshape(-1, 3)])
+                rgb, disp, acc, _ = render(H, W, K, chunk=32768, rays=rays, near=2., far=6., **kw)
+                return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+            return parallel.render_sharded(rows, H, W, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_rays = H * W
+        q_ms, q_pts, q_n = timer.summary()
+        achieved = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12 if q_ms > 0 else 0.0
+        out = {
+            "metric": "rays/sec at 64+128 samples/ray (render)",
+            "value": n_rays * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"lego-shaped {H}x{W} test-view render, 64+128 samples, D=8 W=256 coarse+fine, "
+                                   "fp32, chunk 32768", "rays_per_step": n_rays,
+                       "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)",
+                         "launches": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
+                         "flop_per_point": FLOP_PER_POINT, "points_per_launch": q_pts / max(q_n, 1),
+                         "query_share_of_step": q_ms * 1e-3 / dt},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

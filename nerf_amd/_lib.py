@@ -53,6 +53,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C nerf_amd/csrc` "
                                "(or __graft_entry__.build()); nerf_amd has no CPU fallback")
+        # torch bundles its own HIP runtime (libamdhip64); it must be the one already mapped when
+        # libnrf.so resolves its dependency, or the process ends up with two runtimes and two device states
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)

@@ -1,0 +1,115 @@
+"""NeRF MLP -- counterpart of the reference's network.py.
+
+`NeRF` keeps the reference's constructor, attributes and state_dict keys (real nn.Linear parameters:
+`pts_linears.{i}`, `views_linears.0`, `feature_linear`, `alpha_linear`, `rgb_linear` / `output_linear`;
+network.py:29-44), so checkpoints and optimizer state round-trip.  The arithmetic runs in the fused
+f32-MFMA HIP kernels (nrf_query_fwd / nrf_query_bwd):
+
+  * `forward(x)`            -- x already embedded [P, input_ch + input_ch_views]  (network.py:46-69)
+  * `query_points(...)`     -- raw points + per-ray directions, encoding fused in-kernel; used by
+                               render.run_network when the embedders are the standard ones.
+
+The packed (MFMA-ordered) weight copy is refreshed lazily whenever a parameter's version changes.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _QueryFunction(torch.autograd.Function):
+    """raw = net(points); backward produces parameter gradients with the HIP backward kernels."""
+
+    @staticmethod
+    def forward(ctx, module, key, pts, viewdirs, pts_per_ray, *params):
+        packed = module._packed(key)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad:
+            raw, saved = packed.query_train(pts, viewdirs, pts_per_ray)
+            ctx.module, ctx.key, ctx.pts_per_ray = module, key, pts_per_ray
+            ctx.saved = saved
+            ctx.save_for_backward(pts, viewdirs if viewdirs is not None else pts.new_empty(0))
+            return raw
+        return packed.query(pts, viewdirs, pts_per_ray)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        pts, viewdirs = ctx.saved_tensors
+        packed = ctx.module._packed(ctx.key)
+        grads = packed.query_bwd(g_raw.contiguous(), pts, viewdirs if viewdirs.numel() else None, ctx.pts_per_ray,
+                                 ctx.saved)
+        ctx.saved = None
+        order = [name for name, _ in ctx.module.named_parameters()]
+        return (None, None, None, None, None) + tuple(grads.get(n) for n in order)
+
+
+class NeRF(nn.Module):
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.output_ch = output_ch
+        self.skips = skips
+        self.use_viewdirs = use_viewdirs
+
+        # layer i+1 reads cat[input_pts, h] when i is a skip index (network.py:52-53)
+        widths = [input_ch] + [W + input_ch if i in skips else W for i in range(D - 1)]
+        self.pts_linears = nn.ModuleList([nn.Linear(w_in, W) for w_in in widths])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+        self._packed_cache = {}
+
+    # ------------------------------------------------------------------ packed weights
+    def _packed(self, key):
+        """key = (mode, multires, multires_views)."""
+        pk = self._packed_cache.get(key)
+        if pk is None:
+            params = dict(self.named_parameters())
+            if not self.use_viewdirs:
+                params = {k: v for k, v in params.items() if not k.startswith("views_linears")}
+            mode, L, Lv = key
+            pk = ops.PackedNet(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
+                               list(self.skips), self.use_viewdirs, mode=mode, multires=L, multires_views=Lv)
+            self._packed_cache[key] = pk
+        return pk
+
+    def _apply(self, fn, *args, **kwargs):  # .to()/.cuda() replace parameter tensors: drop stale packed copies
+        self._packed_cache = {}
+        return super()._apply(fn, *args, **kwargs)
+
+    def _params_in_order(self):
+        return [p for _, p in self.named_parameters()]
+
+    # ------------------------------------------------------------------ queries
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, *self._params_in_order())
+        return out.reshape(*lead, out.shape[-1])
+
+    def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
+        """pts [P,3]; viewdirs [P/pts_per_ray, 3] or None -> raw [P, 4|output_ch] (render.py:31-56 fused)."""
+        key = (0, multires, multires_views if self.use_viewdirs else 0)
+        return _QueryFunction.apply(self, key, pts, viewdirs if self.use_viewdirs else None, pts_per_ray,
+                                    *self._params_in_order())
+
+    # ------------------------------------------------------------------ Keras import (network.py:71-99)
+    def load_weights_from_keras(self, weights):
+        assert self.use_viewdirs, "Not implemented if use_viewdirs=False"
+
+        def put(linear, idx):
+            linear.weight.data = torch.from_numpy(np.transpose(weights[idx]))
+            linear.bias.data = torch.from_numpy(np.transpose(weights[idx + 1]))
+        for i in range(self.D):
+            put(self.pts_linears[i], 2 * i)
+        put(self.feature_linear, 2 * self.D)
+        put(self.views_linears[0], 2 * self.D + 2)
+        put(self.rgb_linear, 2 * self.D + 4)
+        put(self.alpha_linear, 2 * self.D + 6)
+        self._packed_cache = {}

@@ -95,6 +95,10 @@ def pe_fwd(x, num_freqs, max_freq_log2, log_sampling=True, include_input=True):
     return out.reshape(*x.shape[:-1], od)
 
 
+def pe_bwd(x, g_out, num_freqs, max_freq_log2, log_sampling=True, include_input=True):
+    raise NotImplementedError("nrf_pe_bwd is not built yet")
+
+
 # ---------------------------------------------------------------- compositing
 def _dirs(rays_d):
     """rays_d may be a strided view into the [N, ncol] ray matrix; pass (base pointer, row stride)."""
@@ -196,3 +200,9 @@ class PackedNet:
         check(_lib.lib().nrf_query_fwd(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
                                        _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _stream()), "nrf_query_fwd")
         return raw
+
+    def query_train(self, pts, viewdirs=None, pts_per_ray=1):
+        raise NotImplementedError("training-mode query (saved activations) is not built yet")
+
+    def query_bwd(self, g_raw, pts, viewdirs, pts_per_ray, saved):
+        raise NotImplementedError("nrf_query_bwd is not built yet")

@@ -189,6 +189,15 @@ def gen_static(out):
             assert torch.equal(raw1, ret["raw"])
             G[f"rr_{name}_raw0"], G[f"rr_{name}_weights0"] = raw0.numpy(), w0.numpy()
             G[f"rr_{name}_z_vals"] = zf.numpy()
+        # default-init ("smooth") nets: a well-conditioned field, where END-TO-END parity holds to 1e-4
+        c_s = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(24))
+        f_s = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(25))
+        rs = fx.blender_rays(128, 10)
+        ret = rr.render_rays(T(rs), c_s, query_fn(e10, e4), 64, retraw=True, perturb=0., N_importance=128,
+                             network_fine=f_s, white_bkgd=True, raw_noise_std=0.)
+        G["rr_smooth_rays"] = rs
+        for k, v in ret.items():
+            G[f"rr_smooth_{k}"] = v.numpy()
         # no viewdirs, no fine net (N_importance=0), 8-column rays
         sd = fx.make_nerf_state(23, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,),
                                 use_viewdirs=False, peaky=True)

@@ -137,6 +137,15 @@ def test_render_rays(gold, name):
                             rtol=1e-4 if k == "disp_map" else 0.0)
 
 
+def test_render_rays_smooth_end_to_end(gold):
+    # default-init nets: end-to-end (own coarse weights -> resampling -> fine pass) within 1e-4 everywhere
+    ret = orc.render_rays(gold["rr_smooth_rays"], orc.Net(fx.make_nerf_state(24)), orc.Net(fx.make_nerf_state(25)),
+                          64, 128, False, True, retraw=True)
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0", "z_std"):
+        np.testing.assert_allclose(ret[k], gold[f"rr_smooth_{k}"], atol=1e-4, rtol=0, err_msg=k)
+    np.testing.assert_allclose(ret["disp_map"], gold["rr_smooth_disp_map"], atol=1e-4, rtol=1e-3)  # a quotient of two small sums
+
+
 def test_render_rays_noview_and_samefine(gold):
     kw = dict(D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,), use_viewdirs=False)
     small = orc.Net(fx.make_nerf_state(23, peaky=True, **kw), **kw)
