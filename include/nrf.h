@@ -84,6 +84,27 @@ int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, float *pa
 int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
                   const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
 
+/* ---- training (train.py:226-243: forward with saved activations, then autograd's backward) ----
+ * Workspaces are caller-allocated; sizes in floats from the *_floats queries (<= 0: unsupported shape).
+ *   acts : inputs and per-layer activations saved by the forward        (~10.1 KB / point at W=256, D=8)
+ *   gbuf : per-layer gradients w.r.t. pre-activations (backward scratch) (~10.0 KB / point)
+ *   slab : per-chunk partial weight gradients (backward scratch)         */
+int64_t nrf_train_acts_floats(const nrf_net_t *net, int64_t n_points);
+int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points);
+int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points);
+
+/* nrf_query_fwd that also fills `acts` (same results bit for bit). */
+int nrf_query_fwd_train(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                        const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
+                        void *stream);
+
+/* K3b  backward of the network query w.r.t. every nn.Linear parameter -- autograd of network.py:46-69.
+ * g_raw [P, 4 | output_ch] = d(loss)/d(raw).  `grads` has the layout of nrf_net_t; its pointers are the
+ * DESTINATION gradient buffers (same shapes as the parameters), which are overwritten, not accumulated. */
+int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                  const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                  void *stream);
+
 /* K4  raw2outputs -- render.py:82-131.  raw [N,S,4], z_vals [N,S], rays_d rows of `d_stride` floats
  * (pass rays+3 with d_stride = ncol to read directions out of the ray matrix), noise NULL or [N,S]
  * (already multiplied by raw_noise_std).  Outputs rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]. */

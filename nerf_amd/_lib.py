@@ -38,6 +38,13 @@ _SIGS = {
     "nrf_mlp_packed_floats": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_mlp_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_query_fwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),
+    "nrf_train_acts_floats": (C.c_int64, [C.POINTER(NrfNet), C.c_int64]),
+    "nrf_train_grads_floats": (C.c_int64, [C.POINTER(NrfNet), C.c_int64]),
+    "nrf_train_slab_floats": (C.c_int64, [C.POINTER(NrfNet), C.c_int64]),
+    "nrf_query_fwd_train": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp,
+                                      vp, vp]),
+    "nrf_query_bwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
+                                C.POINTER(NrfNet), vp]),
     "nrf_composite_fwd": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp,
                                     vp]),
     "nrf_composite_bwd": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp,

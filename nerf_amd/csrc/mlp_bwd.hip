@@ -1,0 +1,414 @@
+// K3b: backward of the fused NeRF MLP on f32 MFMA, gfx950.  Autograd of network.py:46-69 w.r.t. the
+// nn.Linear parameters (train.py:242), in three kinds of launches:
+//
+//  1. dgrad chain (one wave = 32 points, no LDS, no barriers -- the forward's structure run in reverse):
+//     d/d(pre-activation) of every layer, obtained by chaining  g_in^T = W^T g_out^T  on the MFMA with
+//     the accumulators re-used as the next B operand, ReLU masks read back from the saved activations.
+//     Each layer's gradient tile is written to the T8 workspace.
+//  2. wgrad GEMMs:  dW[n][k] = sum_points g[n][p] x[k][p]  contracts over POINTS; both operands are
+//     read from the T8 workspace as whole 1 KiB wave loads (lane (s, c) = 4 points of channel c), a wave
+//     owns a 128x128 block of dW (256 accumulator registers) for a chunk of points and writes a partial slab.
+//     Bias gradients are the row sums of the same A operand.
+//  3. reduce + unpack: sums the slabs over chunks (fixed order: deterministic) and scatters into the
+//     nn.Linear [out, in] gradient layout, undoing the k-space permutation of the input blocks.
+#include "mlp_device.h"
+
+namespace nrf {
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[t][r] = 0.0f;
+}
+
+// store / load accumulator-layout registers into a T8 section of C channels starting at channel c0
+template <int NT>
+__device__ __forceinline__ void store_acc_t8c(const TBuf &tb, uint32_t sec, int C, const f32x16 (&v)[NT]) {
+    const int voff = ((tb.m * C + 4 * tb.h) * 8 + tb.q7) * 4;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+s"(sec));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), tb.rsrc, voff,
+                                                  (int)((sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// head tile: 32 channels starting at channel c0 of a section with C channels; channel c0+o = vals[o] (o < n), else 0
+__device__ __forceinline__ void store_head_tile(const TBuf &tb, uint32_t sec, int C, int c0, const float (&vals)[8],
+                                                int n) {
+    const int voff = ((tb.m * C + c0 + 16 * tb.h) * 8 + tb.q7) * 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (tb.h == 0 && j == o && o < n) v = vals[o];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), tb.rsrc, voff, (int)((sec + j * 8) * 4), 0);
+    }
+}
+
+// acc = act > 0 ? acc : 0, with act read back from the saved activations
+template <int NT>
+__device__ __forceinline__ void relu_mask_t8(const TBuf &ta, uint32_t sec, f32x16 (&g)[NT]) {
+    constexpr int C = 32 * NT;
+    const int voff = ((ta.m * C + 4 * ta.h) * 8 + ta.q7) * 4;
+    asm volatile("" : "+s"(sec));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                ta.rsrc, voff, (int)((sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0));
+            g[t][r] = a > 0.0f ? g[t][r] : 0.0f;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// g[t][r] += vec[channel] * s   (head weight vectors in accumulator order)
+template <int NT>
+__device__ __forceinline__ void axpy_head(f32x16 (&g)[NT], const WBuf &wb, uint32_t vec, float s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 v = wload(wb, wb.h16, (vec + ((t * 4 + gq) * 2) * 4) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[t][4 * gq + i] = fmaf(v[i], s, g[t][4 * gq + i]);
+        }
+}
+
+struct DgradArgs {
+    NetPlan plan;
+    TrainLayout tl;
+    const float *packed;
+    const float *g_raw;  // [P, output_ch]
+    const float *acts;
+    float *gbuf;
+    int64_t n_points;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
+    const NetPlan &pl = a.plan;
+    const TrainLayout &tl = a.tl;
+    const int lane = threadIdx.x & 63, n = lane & 31;
+    WBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.packed), 0, (int)(pl.total_floats * 4), 0x00020000);
+    wb.lane16 = lane * 16;
+    wb.h16 = (lane >> 5) * 16;
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = (a.n_points + 31) >> 5;
+    constexpr int W = 32 * NT;
+
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t p = tile * 32 + n;
+        const bool live = p < a.n_points;
+        TBuf ta = make_tbuf(const_cast<float *>(a.acts) + tile * tl.a_tile, tl.a_tile, lane);
+        TBuf tg = make_tbuf(a.gbuf + tile * tl.g_tile, tl.g_tile, lane);
+        f32x16 g[NT], nx[NT];
+        zero_acc<NT>(g);
+        if (pl.use_viewdirs) {
+            if constexpr (NT >= 2) {
+                float4 gr = live ? reinterpret_cast<const float4 *>(a.g_raw)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float hv[8] = {gr.x, gr.y, gr.z, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, hv, 3);          // d/d(rgb logits): rgb_linear wgrad
+                // through rgb_linear (network.py:64) and the view layer's ReLU
+                f32x16 g2[NT / 2];
+                zero_acc<NT / 2>(g2);
+                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 0 * (NT / 2) * 32, gr.x);
+                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NT / 2) * 32, gr.y);
+                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NT / 2) * 32, gr.z);
+                relu_mask_t8<NT / 2>(ta, (uint32_t)tl.a_hv, g2);
+                store_acc_t8c<NT / 2>(tg, (uint32_t)tl.g_hv, W / 2, g2);
+                // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
+                gemm_hid<NT / 2, NT>(g, g2, wb, (uint32_t)pl.viewsT_w);
+                store_acc_t8c<NT>(tg, (uint32_t)tl.g_feat, W + 32, g);
+                float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);       // d/d(alpha): alpha_linear wgrad
+                // through feature_linear and alpha_linear (network.py:56-57) -> d/d(h_{D-1})
+                zero_acc<NT>(nx);
+                gemm_hid<NT, NT>(nx, g, wb, (uint32_t)pl.featT_w);
+                axpy_head<NT>(nx, wb, (uint32_t)pl.alpha_vec, gr.w);
+                relu_move<NT>(g, nx, false);
+            }
+        } else {
+            float ho[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) ho[o] = (live && o < pl.output_ch) ? a.g_raw[p * pl.output_ch + o] : 0.0f;
+            store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < pl.output_ch) axpy_head<NT>(g, wb, (uint32_t)pl.out_vec + o * NT * 32, ho[o]);
+        }
+        // trunk in reverse (network.py:49-53)
+        for (int l = pl.n_trunk - 1; l >= 0; --l) {
+            relu_mask_t8<NT>(ta, (uint32_t)tl.a_trunk + l * (32 * W), g);
+            store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk + l * (32 * W), W, g);
+            if (l > 0) {
+                zero_acc<NT>(nx);
+                gemm_hid<NT, NT>(nx, g, wb, (uint32_t)(pl.trunkT_base + (int64_t)(l - 1) * pl.trunkT_stride));
+                relu_move<NT>(g, nx, false);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: slab[chunk][n][k] = sum_{points in chunk} G[n][p] * X[k][p]
+struct WgradArgs {
+    const float *gbuf;   // tile stride g_tile
+    const float *acts;   // tile stride a_tile
+    float *slab;         // [nchunks][NP*KP] partial dW, then [nchunks][NP] partial db
+    int64_t g_tile, a_tile, g_sec, a_sec;
+    int64_t ntiles;
+    int32_t Cg, Ca;          // channels in the two T8 sections
+    int32_t n_tiles, k_tiles;  // 32-channel tiles of G (rows of dW) and of X (columns)
+    int32_t chunk_tiles, nchunks;
+};
+
+__global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunk = blockIdx.x;
+    const int k_blks = (a.k_tiles + 3) >> 2, n_blks = (a.n_tiles + 3) >> 2;
+    const int job = blockIdx.y * 4 + wib;
+    if (job >= k_blks * n_blks) return;
+    const int nb = job / k_blks, kb = job - nb * k_blks;
+    const int n0 = nb * 4, k0 = kb * 4;
+    const int na = min(4, a.n_tiles - n0), ka = min(4, a.k_tiles - k0);
+    const int NP = a.n_tiles * 32, KP = a.k_tiles * 32;
+    const int lane_off = ((lane & 31) * 8 + (lane >> 5) * 4) * 4;  // bytes: channel c = lane&31, points 4s..4s+3
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t t0 = (int64_t)chunk * a.chunk_tiles;
+    const int64_t t1 = min(a.ntiles, t0 + a.chunk_tiles);
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.gbuf) + tile * a.g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.acts) + tile * a.a_tile + a.a_sec, 0, a.Ca * 32 * 4, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 A[4], B[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (x < na)
+                    A[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rg, lane_off, ((m * a.Cg + 32 * (n0 + x)) * 8) * 4, 0));
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (y < ka)
+                    B[y] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rx, lane_off, ((m * a.Ca + 32 * (k0 + y)) * 8) * 4, 0));
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (x < na) {
+                    bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        if (y < ka) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
+                        }
+                }
+        }
+    }
+    float *slab = a.slab + (int64_t)chunk * NP * KP;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+        if (x < na) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (y < ka) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = 32 * (n0 + x) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        slab[(int64_t)row * KP + 32 * (k0 + y) + (lane & 31)] = acc[x][y][r];
+                    }
+                }
+            if (kb == 0) {
+                float v = bs[x] + __shfl_xor(bs[x], 32);
+                if (lane < 32) a.slab[(int64_t)a.nchunks * NP * KP + (int64_t)chunk * NP + 32 * (n0 + x) + lane] = v;
+            }
+        }
+}
+
+// dst[n][ch_off + chan(k)] = sum_chunks slab[chunk][row0 + n][k]; dst_b[n] = sum_chunks slab_b[chunk][row0 + n]
+struct ReduceArgs {
+    const float *slab;
+    float *dst_w;   // [n_valid, ld]
+    float *dst_b;   // [n_valid] or null
+    int32_t nchunks, NP, KP, row0, n_valid, ld, ch_off;
+    int32_t x_type, x_param, x_ks;  // how slab column k maps to an input channel (BLK_HIDDEN: identity)
+    int32_t k_valid;                // columns holding live channels (BLK_HIDDEN)
+};
+
+__global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceArgs a) {
+    const int total = a.n_valid * a.KP;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + a.n_valid; e += gridDim.x * blockDim.x) {
+        if (e < total) {
+            int n = e / a.KP, k = e - n * a.KP;
+            int chan = (a.x_type == BLK_HIDDEN) ? (k < a.k_valid ? k : -1) : blk_chan(a.x_type, a.x_param, a.x_ks, k & 1, k >> 1);
+            if (chan < 0) continue;
+            const float *s = a.slab + (int64_t)(a.row0 + n) * a.KP + k;
+            float v = 0.0f;
+            for (int c = 0; c < a.nchunks; ++c) v += s[(int64_t)c * a.NP * a.KP];
+            a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = v;
+        } else if (a.dst_b) {
+            int n = e - total;
+            const float *s = a.slab + (int64_t)a.nchunks * a.NP * a.KP + a.row0 + n;
+            float v = 0.0f;
+            for (int c = 0; c < a.nchunks; ++c) v += s[(int64_t)c * a.NP];
+            a.dst_b[n] = v;
+        }
+    }
+}
+
+struct Bwd {
+    const nrf_net_t *net;
+    const nrf_net_t *grads;
+    NetPlan pl;
+    TrainLayout tl;
+    const float *acts;
+    const float *gbuf;
+    float *slab;
+    int64_t ntiles;
+    int nchunks, chunk_tiles;
+    hipStream_t st;
+
+    // one wgrad GEMM + its reductions.  dsts: up to two (row0, n_valid, dst_w, dst_b) destinations
+    struct Dst { int row0, n_valid; const float *w; const float *b; };
+    int run(int64_t g_sec, int Cg, int n_tiles, int64_t a_sec, int Ca, int k_tiles, int x_type, int x_param, int x_ks,
+            int k_valid, int ld, int ch_off, const Dst *dsts, int ndst) {
+        WgradArgs w{};
+        w.gbuf = gbuf; w.acts = acts; w.slab = slab;
+        w.g_tile = tl.g_tile; w.a_tile = tl.a_tile; w.g_sec = g_sec; w.a_sec = a_sec;
+        w.ntiles = ntiles; w.Cg = Cg; w.Ca = Ca; w.n_tiles = n_tiles; w.k_tiles = k_tiles;
+        w.chunk_tiles = chunk_tiles; w.nchunks = nchunks;
+        int jobs = ((n_tiles + 3) / 4) * ((k_tiles + 3) / 4);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(nchunks, (jobs + 3) / 4), dim3(256), 0, st, w);
+        for (int i = 0; i < ndst; ++i) {
+            ReduceArgs r{};
+            r.slab = slab; r.dst_w = const_cast<float *>(dsts[i].w); r.dst_b = const_cast<float *>(dsts[i].b);
+            r.nchunks = nchunks; r.NP = n_tiles * 32; r.KP = k_tiles * 32; r.row0 = dsts[i].row0;
+            r.n_valid = dsts[i].n_valid; r.ld = ld; r.ch_off = ch_off;
+            r.x_type = x_type; r.x_param = x_param; r.x_ks = x_ks; r.k_valid = k_valid;
+            int total = r.n_valid * (r.KP + 1);
+            hipLaunchKernelGGL(reduce_unpack_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, r);
+        }
+        return check_launch("nrf_query_bwd (wgrad)");
+    }
+};
+
+}  // namespace nrf
+
+using namespace nrf;
+
+static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles) {
+    int64_t nchunks = ntiles < 256 ? ntiles : 256;
+    *chunk_tiles = (int)((ntiles + nchunks - 1) / nchunks);
+    return (ntiles + *chunk_tiles - 1) / *chunk_tiles;
+}
+
+extern "C" int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points) {
+    if (!net || net->W % 32 || n_points < 0) return -1;
+    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    return ((n_points + 31) / 32) * tl.g_tile;
+}
+
+extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points) {
+    if (!net || net->W % 32 || n_points < 0) return -1;
+    int ct;
+    int64_t nchunks = pick_chunks((n_points + 31) / 32, &ct);
+    int64_t np = net->W + 32, kp = net->W;  // the largest GEMM: (feature + alpha row) x hidden
+    if (kp < 64) kp = 64;
+    return nchunks * (np * kp + np);
+}
+
+extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                             const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                             void *stream) {
+    NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
+    NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
+    Planner P{};
+    const char *e = plan_net(P, net, emb, 0);
+    if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: %s", e);
+    if (n_points == 0) return NRF_OK;
+    const NetPlan &pl = P.plan;
+    const int nt = pl.nt, W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
+    hipStream_t st = as_stream(stream);
+    DgradArgs d{};
+    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs);
+    d.packed = packed; d.g_raw = g_raw; d.acts = acts; d.gbuf = gbuf; d.n_points = n_points;
+    const int64_t ntiles = (n_points + 31) / 32;
+    int blocks = (int)((ntiles + 3) / 4);
+    if (blocks > 256) blocks = 256;
+    switch (nt) {
+        case 8: hipLaunchKernelGGL(dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 4: hipLaunchKernelGGL(dgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 2: hipLaunchKernelGGL(dgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, d); break;
+        default: return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: W = %d has no fused kernel", W);
+    }
+    int rc = check_launch("nrf_query_bwd (dgrad)");
+    if (rc) return rc;
+
+    Bwd B{};
+    B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
+    B.ntiles = ntiles; B.st = st;
+    B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles);
+    const TrainLayout &tl = d.tl;
+    const int xk = 2 * kKsX / 32, dk = 2 * kKsD / 32;  // 32-channel tiles of the k-space input blocks
+    for (int l = 0; l < D; ++l) {
+        NRF_REQUIRE(grads->pts_w[l] && grads->pts_b[l], "nrf_query_bwd: grads->pts_w/pts_b[%d] is null", l);
+        const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * W;
+        bool skip = l > 0 && ((net->skips_mask >> (l - 1)) & 1);
+        int ld = l == 0 ? ic : (W + (skip ? ic : 0));
+        Bwd::Dst dst{0, W, grads->pts_w[l], grads->pts_b[l]};
+        if (l == 0 || skip) {  // columns fed by the position input block
+            rc = B.run(gsec, W, nt, tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, ld, 0, &dst, 1);
+            if (rc) return rc;
+        }
+        if (l > 0) {
+            rc = B.run(gsec, W, nt, tl.a_trunk + (int64_t)(l - 1) * 32 * W, W, nt, BLK_HIDDEN, 0, 0, W, ld,
+                       skip ? ic : 0, &dst, 1);
+            if (rc) return rc;
+        }
+    }
+    const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * 32 * W;
+    if (pl.use_viewdirs) {
+        NRF_REQUIRE(grads->feature_w && grads->feature_b && grads->alpha_w && grads->alpha_b && grads->views_w &&
+                    grads->views_b && grads->rgb_w && grads->rgb_b, "nrf_query_bwd: a head gradient pointer is null");
+        Bwd::Dst fd[2] = {{0, W, grads->feature_w, grads->feature_b}, {W, 1, grads->alpha_w, grads->alpha_b}};
+        rc = B.run(tl.g_feat, W + 32, nt + 1, a_last, W, nt, BLK_HIDDEN, 0, 0, W, W, 0, fd, 2);
+        if (rc) return rc;
+        Bwd::Dst vd{0, W / 2, grads->views_w, grads->views_b};
+        rc = B.run(tl.g_hv, W / 2, nt / 2, tl.a_feat, W, nt, BLK_HIDDEN, 0, 0, W, W + icv, 0, &vd, 1);
+        if (rc) return rc;
+        rc = B.run(tl.g_hv, W / 2, nt / 2, tl.a_din, 2 * kKsD, dk, pl.d_type, pl.d_param, kKsD, 0, W + icv, W, &vd, 1);
+        if (rc) return rc;
+        Bwd::Dst rd{0, 3, grads->rgb_w, grads->rgb_b};
+        rc = B.run(tl.g_head, 32, 1, tl.a_hv, W / 2, nt / 2, BLK_HIDDEN, 0, 0, W / 2, W / 2, 0, &rd, 1);
+        if (rc) return rc;
+    } else {
+        NRF_REQUIRE(grads->out_w && grads->out_b, "nrf_query_bwd: grads->out_w/out_b is null");
+        Bwd::Dst od{0, pl.output_ch, grads->out_w, grads->out_b};
+        rc = B.run(tl.g_head, 32, 1, a_last, W, nt, BLK_HIDDEN, 0, 0, W, W, 0, &od, 1);
+        if (rc) return rc;
+    }
+    return NRF_OK;
+}

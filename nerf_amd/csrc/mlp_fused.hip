@@ -12,306 +12,9 @@
 //     dot products (VALU) finished with one cross-half shuffle;
 //   * sin/cos use the accurate range-reducing device functions (arguments reach ~3000 rad).
 // The kernel is MFMA-bound: 593 920 MAC per point issued (593 408 algorithmic, 99.9 %).
-#include "nrf_common.h"
-#include "mlp_layout.h"
+#include "mlp_device.h"
 
 namespace nrf {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------
-// weight packing
-struct PackSec {
-    const float *src;   // nn.Linear weight [n_out, ld] (or bias [n_out])
-    int64_t dst;        // offset in floats
-    int32_t kind;       // 0 gemm block, 1 bias, 2 head vectors, 3 plain copy, 4 zero fill
-    int32_t ld, n_out, nt_out;
-    int32_t blk_type, blk_param, blk_ks, ch_off;
-    int32_t count;      // floats in this section
-    int32_t pad_;
-};
-constexpr int kMaxSecs = 56;
-struct PackArgs {
-    PackSec sec[kMaxSecs];
-    int32_t nsec;
-};
-
-__global__ void __launch_bounds__(256) pack_kernel(PackArgs a, float *__restrict__ packed) {
-    const PackSec &s = a.sec[blockIdx.y];
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < s.count; e += gridDim.x * blockDim.x) {
-        float v = 0.0f;
-        if (s.kind == 0) {  // [G][t][lane][i]
-            int i = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
-            int t = rest % s.nt_out, G = rest / s.nt_out;
-            int h = lane >> 5, n = 32 * t + (lane & 31);
-            int c = blk_chan(s.blk_type, s.blk_param, s.blk_ks, h, 4 * G + i);
-            if (c >= 0 && n < s.n_out) v = s.src[(int64_t)n * s.ld + s.ch_off + c];
-        } else if (s.kind == 1) {  // bias [t][g][h][i]
-            int i = e & 3, h = (e >> 2) & 1, g = (e >> 3) & 3, t = e >> 5;
-            int n = 32 * t + 8 * g + 4 * h + i;
-            if (n < s.n_out) v = s.src[n];
-        } else if (s.kind == 2) {  // head vectors [o][t][g][h][i] over nt_out (= nt_in of the head) tiles
-            int per = s.nt_out * 32;
-            int o = e / per, q = e - o * per;
-            int i = q & 3, h = (q >> 2) & 1, g = (q >> 3) & 3, t = q >> 5;
-            v = s.src[(int64_t)o * s.ld + s.ch_off + 32 * t + 8 * g + 4 * h + i];
-        } else if (s.kind == 3) {
-            v = s.src[e];
-        }
-        packed[s.dst + e] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// host planner
-struct Planner {
-    NetPlan plan;
-    PackArgs pack;
-    int64_t cur = 0;
-    bool want_pack;
-    const char *err = nullptr;
-
-    int64_t alloc(int64_t n) {
-        int64_t o = cur;
-        cur += (n + 3) & ~int64_t(3);  // keep every section 16-byte aligned
-        return o;
-    }
-    void add(PackSec s) {
-        if (pack.nsec >= kMaxSecs) { err = "too many weight sections"; return; }
-        pack.sec[pack.nsec++] = s;
-    }
-    int64_t gemm_block(const float *w, int ld, int n_out, int nt_out, int type, int param, int ks, int ch_off) {
-        int count = (ks / 4) * nt_out * 256;
-        int64_t o = alloc(count);
-        add(PackSec{w, o, 0, ld, n_out, nt_out, type, param, ks, ch_off, count, 0});
-        return o;
-    }
-    int64_t bias(const float *b, int n_out, int nt_out) {
-        int count = nt_out * 32;
-        int64_t o = alloc(count);
-        add(PackSec{b, o, 1, 0, n_out, nt_out, 0, 0, 0, 0, count, 0});
-        return o;
-    }
-    void head(const float *w, const float *b, int ld, int n_out, int nt_in, int ch_off, int64_t &vec,
-              int64_t &bias_off) {
-        int count = n_out * nt_in * 32;
-        vec = alloc(count);
-        add(PackSec{w, vec, 2, ld, n_out, nt_in, 0, 0, 0, ch_off, count, 0});
-        bias_off = alloc(n_out);
-        add(PackSec{b, bias_off, 3, 0, n_out, 0, 0, 0, 0, 0, n_out, 0});
-    }
-    void zeros(int64_t count) {  // a section the kernels never read with live data; keep it defined
-        int64_t o = alloc(count);
-        add(PackSec{nullptr, o, 4, 0, 0, 0, 0, 0, 0, 0, (int32_t)count, 0});
-    }
-};
-
-// Builds the plan for one NeRF-shaped net.  time_ch > 0: deformation ("_time") net whose first layer
-// also takes gamma(t) (vanilla_dynamic/network.py:254-305) and whose head is out_w/out_b (W -> 3).
-static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t *emb, int time_ch) {
-    NetPlan &pl = P.plan;
-    const int W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
-    if (W < 32 || W > 256 || W % 32) return "W must be a multiple of 32 in [32, 256]";
-    if (D < 1 || D > NRF_MAX_D) return "D must be in [1, 16]";
-    if (net->skips_mask >> (D - 1)) return "a skip at the last trunk layer is not supported (nor by the reference)";
-    const bool views = net->use_viewdirs != 0 && time_ch == 0;
-    if (views && (W / 2) % 32) return "use_viewdirs needs W/2 to be a multiple of 32";
-    pl.nt = W / 32;
-    pl.n_trunk = D;
-    pl.use_viewdirs = views;
-    pl.output_ch = time_ch ? 3 : (views ? 4 : net->output_ch);
-    if (pl.output_ch < 1 || pl.output_ch > kMaxHeadOut) return "output_ch must be in [1, 8]";
-    if (emb->mode == 0) {
-        if (ic != 3 + 6 * emb->multires || emb->multires < 0 || emb->multires > 10)
-            return "fused encoding needs input_ch == 3 + 6*multires, multires <= 10";
-        pl.x_type = BLK_PE3; pl.x_param = emb->multires;
-        if (views) {
-            if (icv != 3 + 6 * emb->multires_views || emb->multires_views < 0 || emb->multires_views > 4)
-                return "fused encoding needs input_ch_views == 3 + 6*multires_views, multires_views <= 4";
-            pl.d_type = BLK_PE3; pl.d_param = emb->multires_views;
-        }
-        if (time_ch) {
-            if (time_ch != 1 + 2 * emb->multires_time || emb->multires_time < 0 || emb->multires_time > 10)
-                return "fused encoding needs input_ch_time == 1 + 2*multires_time, multires_time <= 10";
-            pl.t_type = BLK_PE1; pl.t_param = emb->multires_time;
-        }
-    } else {
-        if (ic < 1 || ic > 2 * kKsX) return "embedded input: input_ch must be in [1, 64]";
-        pl.x_type = BLK_RAW; pl.x_param = ic;
-        if (views) {
-            if (icv < 1 || icv > 2 * kKsD) return "embedded input: input_ch_views must be in [1, 32]";
-            pl.d_type = BLK_RAW; pl.d_param = icv;
-        }
-        if (time_ch) {
-            if (time_ch > 2 * kKsT) return "embedded input: input_ch_time must be <= 24";
-            pl.t_type = BLK_RAW; pl.t_param = time_ch;
-        }
-    }
-    const int nt = pl.nt;
-    {   // layer 0 (network.py:49-51 with h = input_pts)
-        int ld = ic + time_ch;
-        pl.l0_w = P.gemm_block(net->pts_w[0], ld, W, nt, pl.x_type, pl.x_param, kKsX, 0);
-        if (time_ch) pl.l0_w2 = P.gemm_block(net->pts_w[0], ld, W, nt, pl.t_type, pl.t_param, kKsT, ic);
-        pl.l0_b = P.bias(net->pts_b[0], W, nt);
-    }
-    pl.trunk_base = P.cur;
-    pl.trunk_stride = nt * 32 + 4 * nt * nt * 256 + (kKsX / 4) * nt * 256;
-    pl.skip_in_mask = 0;
-    for (int i = 1; i < D; ++i) {
-        bool skip = (net->skips_mask >> (i - 1)) & 1;  // network.py:52-53: layer i reads cat[input_pts, h]
-        int ld = W + (skip ? ic : 0);
-        int64_t slot = P.cur;
-        P.bias(net->pts_b[i], W, nt);
-        P.gemm_block(net->pts_w[i], ld, W, nt, BLK_HIDDEN, 0, 16 * nt, skip ? ic : 0);
-        if (skip) {
-            pl.skip_in_mask |= 1 << i;
-            P.gemm_block(net->pts_w[i], ld, W, nt, pl.x_type, pl.x_param, kKsX, 0);
-        } else {
-            P.zeros((kKsX / 4) * nt * 256);
-        }
-        if (P.cur - slot != pl.trunk_stride) return "internal: trunk slot size mismatch";
-    }
-    if (views) {
-        P.head(net->alpha_w, net->alpha_b, W, 1, nt, 0, pl.alpha_vec, pl.alpha_b);                  // network.py:56
-        pl.feat_w = P.gemm_block(net->feature_w, W, W, nt, BLK_HIDDEN, 0, 16 * nt, 0);               // network.py:57
-        pl.feat_b = P.bias(net->feature_b, W, nt);
-        pl.views_w_hid = P.gemm_block(net->views_w, W + icv, W / 2, nt / 2, BLK_HIDDEN, 0, 16 * nt, 0);  // :58-62
-        pl.views_w_in = P.gemm_block(net->views_w, W + icv, W / 2, nt / 2, pl.d_type, pl.d_param, kKsD, W);
-        pl.views_b = P.bias(net->views_b, W / 2, nt / 2);
-        P.head(net->rgb_w, net->rgb_b, W / 2, 3, nt / 2, 0, pl.rgb_vec, pl.rgb_b);                   // network.py:64
-    } else {
-        P.head(net->out_w, net->out_b, W, pl.output_ch, nt, 0, pl.out_vec, pl.out_b);               // network.py:67
-    }
-    pl.total_floats = P.cur;
-    return P.err;
-}
-
-// ------------------------------------------------------------------------------------------------
-// device side
-//
-// All weight traffic goes through ONE buffer descriptor (wave-uniform, in SGPRs): address =
-// descriptor base + SGPR byte offset + per-lane VGPR offset.  With plain pointers the compiler
-// materialises a 64-bit VGPR address per load of the unrolled layer and spills them.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct WBuf {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int lane16;  // lane * 16: per-lane byte offset inside a 1 KiB wave load
-    int h16;     // (lane >> 5) * 16: per-half offset into bias / head-vector tables
-};
-
-__device__ __forceinline__ f32x4 wload(const WBuf &wb, int voff, uint32_t soff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wb.rsrc, voff, (int)soff_bytes, 0));
-}
-__device__ __forceinline__ float wload1(const WBuf &wb, uint32_t soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.rsrc, 0, (int)soff_bytes, 0));
-}
-
-// `b` etc. below are offsets in FLOATS from the start of the packed buffer (wave-uniform).
-template <int NT_OUT>
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[NT_OUT], const WBuf &wb, uint32_t b) {
-#pragma unroll
-    for (int t = 0; t < NT_OUT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = wload(wb, wb.h16, (b + ((t * 4 + g) * 2) * 4) * 4);
-            acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
-        }
-}
-
-// One k-group (4 k-steps) of weights for NT_OUT output tiles: NT_OUT coalesced 1 KiB wave loads.
-template <int NT_OUT>
-__device__ __forceinline__ void load_wgroup(f32x4 (&wv)[NT_OUT], const WBuf &wb, uint32_t w, int G) {
-#pragma unroll
-    for (int t = 0; t < NT_OUT; ++t) wv[t] = wload(wb, wb.lane16, (w + (G * NT_OUT + t) * 256) * 4);
-}
-
-// The k loop is fully unrolled (operand registers must be statically indexed).  Left alone, the
-// scheduler hoists every weight load of the layer to the top and spills; the sched_barrier pins a
-// one-group-ahead software pipeline instead: group G+1's loads are in flight during group G's
-// 4*NT_OUT MFMAs (>= 1024 cycles, several L2 latencies).
-#define NRF_GEMM_BODY(NG, SRC)                                                                          \
-    f32x4 wa[NT_OUT], wb_[NT_OUT];                                                                      \
-    load_wgroup<NT_OUT>(wa, wb, w, 0);                                                                  \
-    _Pragma("unroll") for (int G = 0; G < (NG); ++G) {                                                  \
-        f32x4(&cur)[NT_OUT] = (G & 1) ? wb_ : wa;                                                       \
-        f32x4(&nxt)[NT_OUT] = (G & 1) ? wa : wb_;                                                       \
-        if (G + 1 < (NG)) load_wgroup<NT_OUT>(nxt, wb, w, G + 1);                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        _Pragma("unroll") for (int t = 0; t < NT_OUT; ++t) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][i], SRC, acc[t], 0, 0, 0);             \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-    }
-
-// acc[t] += W_block * xin   (input block held as one register per k-step)
-template <int KS, int NT_OUT>
-__device__ __forceinline__ void gemm_in(f32x16 (&acc)[NT_OUT], const float (&xin)[KS], const WBuf &wb, uint32_t w) {
-    NRF_GEMM_BODY(KS / 4, xin[4 * G + i])
-}
-
-// acc[t] += W_block * hin   (input = previous layer's accumulators, used as they stand)
-template <int NT_IN, int NT_OUT>
-__device__ __forceinline__ void gemm_hid(f32x16 (&acc)[NT_OUT], const f32x16 (&hin)[NT_IN], const WBuf &wb,
-                                         uint32_t w) {
-    NRF_GEMM_BODY(4 * NT_IN, hin[G >> 2][4 * (G & 3) + i])
-}
-
-template <int NT>
-__device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], bool relu) {
-    const float lo = relu ? 0.0f : -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[t][r] = fmaxf(src[t][r], lo);
-}
-
-// lane-local part of  sum_c vec[c] * h[c]  over this lane's channels, then the other half's part
-template <int NT_IN>
-__device__ __forceinline__ float head_dot(const f32x16 (&hin)[NT_IN], const WBuf &wb, uint32_t vec) {
-    float s = 0.0f;
-#pragma unroll
-    for (int t = 0; t < NT_IN; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = wload(wb, wb.h16, (vec + ((t * 4 + g) * 2) * 4) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s = fmaf(v[i], hin[t][4 * g + i], s);
-        }
-    return s + __shfl_xor(s, 32);
-}
-
-__device__ __forceinline__ float pow2i(int f) { return __int_as_float((127 + f) << 23); }
-
-// gamma(v) for a 3-vector into the static k-step slots of BLK_PE3 (see blk_chan)
-template <int KS>
-__device__ __forceinline__ void fill_pe3(float (&xin)[KS], float x, float y, float z, int L, int h) {
-    constexpr int NPAIR = (KS - 2) / 6;
-#pragma unroll
-    for (int j = 0; j < NPAIR; ++j) {
-        const int f = 2 * j + h;
-        const bool valid = f < L;
-        const float sc = valid ? pow2i(f) : 0.0f;
-        float sx, cx, sy, cy, sz, cz;
-        sincosf(x * sc, &sx, &cx);   // x * 2^f is exact, as in positional_encoding.py:29
-        sincosf(y * sc, &sy, &cy);
-        sincosf(z * sc, &sz, &cz);
-        xin[6 * j + 0] = sx; xin[6 * j + 1] = sy; xin[6 * j + 2] = sz;
-        xin[6 * j + 3] = valid ? cx : 0.0f; xin[6 * j + 4] = valid ? cy : 0.0f; xin[6 * j + 5] = valid ? cz : 0.0f;
-    }
-#pragma unroll
-    for (int s = 6 * NPAIR; s < KS - 2; ++s) xin[s] = 0.0f;
-    xin[KS - 2] = h == 0 ? x : y;
-    xin[KS - 1] = h == 0 ? z : 0.0f;
-}
-
-template <int KS>
-__device__ __forceinline__ void fill_raw(float (&xin)[KS], const float *__restrict__ row, int n, int h) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        int c = 2 * s + h;
-        xin[s] = c < n ? row[c] : 0.0f;
-    }
-}
 
 struct QueryArgs {
     NetPlan plan;
@@ -321,9 +24,11 @@ struct QueryArgs {
     float *raw;             // [P, output_ch]
     int64_t n_points;
     int32_t pts_per_ray, x_stride, input_ch, pad_;
+    float *acts;            // training mode: [n_tiles][tl.a_tile] saved inputs / activations (T8 sections)
+    TrainLayout tl;
 };
 
-template <int NT, bool EMB>
+template <int NT, bool EMB, bool TRAIN>
 __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
     const NetPlan &pl = a.plan;
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -331,7 +36,9 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.packed), 0, (int)(pl.total_floats * 4), 0x00020000);
     wb.lane16 = lane * 16;
     wb.h16 = h * 16;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // readfirstlane: make the wave index (and everything derived from it: tile, buffer descriptors)
+    // provably wave-uniform, or every buffer op through a per-tile descriptor gets a waterfall loop
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t ntiles = (a.n_points + 31) >> 5;
     const uint32_t hid_off = NT * 32, skip_off = NT * 32 + 4 * NT * NT * 256;
@@ -354,28 +61,38 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             }
         }
 
+        TBuf tb;
+        if constexpr (TRAIN) {
+            tb = make_tbuf(a.acts + tile * a.tl.a_tile, a.tl.a_tile, lane);
+            store_in_t8<kKsX>(tb, (uint32_t)a.tl.a_xin, xin);
+            if (pl.use_viewdirs) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
+        }
         f32x16 hin[NT], acc[NT];
         // trunk (network.py:48-53)
         load_bias<NT>(acc, wb, (uint32_t)pl.l0_b);
         gemm_in<kKsX, NT>(acc, xin, wb, (uint32_t)pl.l0_w);
         relu_move<NT>(hin, acc, true);
+        if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk, hin);
         for (int l = 1; l < pl.n_trunk; ++l) {
             const uint32_t slot = (uint32_t)(pl.trunk_base + (int64_t)(l - 1) * pl.trunk_stride);
             load_bias<NT>(acc, wb, slot);
             if ((pl.skip_in_mask >> l) & 1) gemm_in<kKsX, NT>(acc, xin, wb, slot + skip_off);
             gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
             relu_move<NT>(hin, acc, true);
+            if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk + l * (32 * 32 * NT), hin);
         }
         if (pl.use_viewdirs) {
             if constexpr (NT >= 2) {
                 const float alpha = head_dot<NT>(hin, wb, (uint32_t)pl.alpha_vec) + wload1(wb, (uint32_t)pl.alpha_b * 4);
                 load_bias<NT>(acc, wb, (uint32_t)pl.feat_b);                                     // network.py:57
                 gemm_hid<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w);
+                if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_feat, acc);
                 f32x16 acc2[NT / 2];
                 load_bias<NT / 2>(acc2, wb, (uint32_t)pl.views_b);                               // network.py:58-62
                 gemm_hid<NT, NT / 2>(acc2, acc, wb, (uint32_t)pl.views_w_hid);
                 gemm_in<kKsD, NT / 2>(acc2, din, wb, (uint32_t)pl.views_w_in);
                 relu_move<NT / 2>(acc2, acc2, true);
+                if constexpr (TRAIN) store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);
                 const uint32_t rv = (uint32_t)pl.rgb_vec, rb = (uint32_t)pl.rgb_b * 4;
                 float4 o;                                                                        // network.py:64-65
                 o.x = head_dot<NT / 2>(acc2, wb, rv + 0 * (NT / 2) * 32) + wload1(wb, rb + 0);
@@ -399,7 +116,10 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
     int64_t ntiles = (a.n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // 512 registers per lane -> one 4-wave workgroup per CU
-    hipLaunchKernelGGL((query_fwd_kernel<NT, EMB>), dim3(blocks), dim3(256), 0, st, a);
+    if (a.acts)
+        hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, true>), dim3(blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false>), dim3(blocks), dim3(256), 0, st, a);
     return check_launch("nrf_query_fwd");
 }
 
@@ -427,9 +147,9 @@ extern "C" int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb
     return check_launch("nrf_mlp_pack_weights");
 }
 
-extern "C" int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
-                             const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw,
-                             void *stream) {
+static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                          const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
+                          void *stream) {
     NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_fwd: negative n_points");
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
@@ -450,6 +170,8 @@ extern "C" int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const
                     pts_per_ray);
     }
     a.pts_per_ray = pts_per_ray > 0 ? pts_per_ray : 1;
+    a.acts = acts;
+    a.tl = make_train_layout(P.plan.nt, P.plan.n_trunk, P.plan.use_viewdirs);
     hipStream_t st = as_stream(stream);
     const bool emb1 = emb->mode != 0;
     switch (P.plan.nt) {
@@ -459,4 +181,23 @@ extern "C" int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const
         default:
             return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d has no fused kernel (64, 128, 256 do)", net->W);
     }
+}
+
+extern "C" int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                             const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw,
+                             void *stream) {
+    return query_fwd_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, nullptr, stream);
+}
+
+extern "C" int64_t nrf_train_acts_floats(const nrf_net_t *net, int64_t n_points) {
+    if (!net || net->W % 32 || n_points < 0) return -1;
+    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    return ((n_points + 31) / 32) * tl.a_tile;
+}
+
+extern "C" int nrf_query_fwd_train(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed,
+                                   const float *pts, const float *viewdirs, int64_t n_points, int32_t pts_per_ray,
+                                   float *raw, float *acts, void *stream) {
+    NRF_REQUIRE(acts, "nrf_query_fwd_train: acts workspace is null");
+    return query_fwd_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream);
 }

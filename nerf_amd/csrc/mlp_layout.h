@@ -91,7 +91,50 @@ struct NetPlan {
     int64_t alpha_vec, alpha_b;         // alpha_linear (network.py:56)
     int64_t rgb_vec, rgb_b;             // rgb_linear (network.py:64)
     int64_t out_vec, out_b;             // output_linear (network.py:67) or _time_out (deformation net)
+    int64_t trunkT_base, trunkT_stride; // W^T (hidden part) of trunk layer l >= 1: trunkT_base + (l-1)*stride
+    int64_t featT_w, viewsT_w;          // W^T of feature_linear; of views_linears[0][:, :W]
     int64_t total_floats;
 };
+
+// Training workspace, per 32-point tile.  Every section is a [4][C][8] block ("T8"): element
+// (channel c, point q of the tile) at ((q >> 3) * C + c) * 8 + (q & 7).  The forward kernel writes it from
+// its accumulator registers (32-byte runs), the backward chain reads it back the same way, and the
+// weight-gradient GEMM -- which contracts over POINTS -- reads whole 1 KiB pieces of it as MFMA operands
+// (lane (s, c) takes the 4 points 8m+4s.. of channel c).
+struct TrainLayout {
+    int32_t nt, n_trunk, use_viewdirs, pad_;
+    // activations (floats from the tile's base)
+    int64_t a_xin, a_din, a_tin;     // input blocks in k-step space: channel 2*step + half (64 / 32 / 24 ch)
+    int64_t a_trunk;                 // D sections of W channels: post-ReLU outputs of trunk layer l
+    int64_t a_feat, a_hv;            // feature_linear output (W), views layer output (W/2, post-ReLU)
+    int64_t a_tile;                  // floats per tile
+    // gradients w.r.t. pre-activations
+    int64_t g_trunk;                 // D sections of W
+    int64_t g_feat;                  // W + 32: the extra tile's row 0 is d/d(alpha)
+    int64_t g_hv;                    // W/2
+    int64_t g_head;                  // 32: rows 0..2 d/d(rgb)  (or d/d(output_linear out) rows 0..output_ch-1)
+    int64_t g_tile;
+};
+
+NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
+    TrainLayout t{};
+    t.nt = nt; t.n_trunk = D; t.use_viewdirs = use_viewdirs;
+    const int W = 32 * nt;
+    int64_t c = 0;
+    t.a_xin = c; c += 32 * 2 * kKsX;
+    t.a_din = c; c += 32 * 2 * kKsD;
+    t.a_tin = c; c += 32 * 2 * kKsT;
+    t.a_trunk = c; c += (int64_t)32 * W * D;
+    t.a_feat = c; c += 32 * W;
+    t.a_hv = c; c += 32 * (W / 2);
+    t.a_tile = c;
+    c = 0;
+    t.g_trunk = c; c += (int64_t)32 * W * D;
+    t.g_feat = c; c += 32 * (W + 32);
+    t.g_hv = c; c += 32 * (W / 2);
+    t.g_head = c; c += 32 * 32;
+    t.g_tile = c;
+    return t;
+}
 
 }  // namespace nrf

@@ -26,20 +26,17 @@ class _QueryFunction(torch.autograd.Function):
         packed = module._packed(key)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if need_grad:
-            raw, saved = packed.query_train(pts, viewdirs, pts_per_ray)
-            ctx.module, ctx.key, ctx.pts_per_ray = module, key, pts_per_ray
-            ctx.saved = saved
-            ctx.save_for_backward(pts, viewdirs if viewdirs is not None else pts.new_empty(0))
+            raw, acts = packed.query_train(pts, viewdirs, pts_per_ray)
+            ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
+            ctx.save_for_backward(acts)
             return raw
         return packed.query(pts, viewdirs, pts_per_ray)
 
     @staticmethod
     def backward(ctx, g_raw):
-        pts, viewdirs = ctx.saved_tensors
+        (acts,) = ctx.saved_tensors
         packed = ctx.module._packed(ctx.key)
-        grads = packed.query_bwd(g_raw.contiguous(), pts, viewdirs if viewdirs.numel() else None, ctx.pts_per_ray,
-                                 ctx.saved)
-        ctx.saved = None
+        grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts)
         order = [name for name, _ in ctx.module.named_parameters()]
         return (None, None, None, None, None) + tuple(grads.get(n) for n in order)
 

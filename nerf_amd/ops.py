@@ -202,7 +202,40 @@ class PackedNet:
         return raw
 
     def query_train(self, pts, viewdirs=None, pts_per_ray=1):
-        raise NotImplementedError("training-mode query (saved activations) is not built yet")
+        """Forward that also saves inputs/activations for query_bwd -> (raw, saved workspace)."""
+        self.refresh()
+        pts = _f32(pts, "pts")
+        P = pts.shape[0]
+        raw = torch.empty((P, self.out_ch), device=pts.device, dtype=torch.float32)
+        n = _lib.lib().nrf_train_acts_floats(C.byref(self.net), P)
+        acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
+        if viewdirs is not None:
+            viewdirs = _f32(viewdirs, "viewdirs")
+        check(_lib.lib().nrf_query_fwd_train(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                             _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _ptr(acts), _stream()),
+              "nrf_query_fwd_train")
+        return raw, acts
 
-    def query_bwd(self, g_raw, pts, viewdirs, pts_per_ray, saved):
-        raise NotImplementedError("nrf_query_bwd is not built yet")
+    def query_bwd(self, g_raw, n_points, acts):
+        """-> dict name -> gradient tensor (same shapes as the parameters)."""
+        g_raw = _f32(g_raw, "g_raw")
+        dev = g_raw.device
+        lib = _lib.lib()
+        gbuf = torch.empty((max(lib.nrf_train_grads_floats(C.byref(self.net), n_points), 1),), device=dev)
+        slab = torch.empty((max(lib.nrf_train_slab_floats(C.byref(self.net), n_points), 1),), device=dev)
+        grads = {k: torch.empty_like(v, dtype=torch.float32).contiguous() for k, v in self.params.items()}
+        gn = NrfNet()
+        g = lambda k: C.c_void_p(grads[k].data_ptr())  # noqa: E731
+        n = self.net
+        for i in range(n.D):
+            gn.pts_w[i], gn.pts_b[i] = g(f"pts_linears.{i}.weight"), g(f"pts_linears.{i}.bias")
+        if n.use_viewdirs:
+            gn.views_w, gn.views_b = g("views_linears.0.weight"), g("views_linears.0.bias")
+            gn.feature_w, gn.feature_b = g("feature_linear.weight"), g("feature_linear.bias")
+            gn.alpha_w, gn.alpha_b = g("alpha_linear.weight"), g("alpha_linear.bias")
+            gn.rgb_w, gn.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
+        else:
+            gn.out_w, gn.out_b = g("output_linear.weight"), g("output_linear.bias")
+        check(lib.nrf_query_bwd(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw), _ptr(acts),
+                                _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()), "nrf_query_bwd")
+        return grads

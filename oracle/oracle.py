@@ -184,7 +184,10 @@ class Net:
         return out
 
     # numpy forward with saved activations + backward: the gradient oracle (autograd of network.py:46-69)
-    def forward_backward(self, x, g_out):
+    def forward_backward(self, x, g_out, masks=None):
+        """masks: optional {"trunk": [D x bool[P,W]], "hv": bool[P,W/2]} ReLU gates to use instead of the
+        oracle's own (a pre-activation within rounding of 0 can gate differently in f32 and f64; a gradient
+        check should not depend on that coin flip)."""
         sd, pre = self.sd, self.prefix
         x = _f(x).astype(np.float64)
         xp, xv = x[:, :self.input_ch], x[:, self.input_ch:]
@@ -205,7 +208,7 @@ class Net:
         out = np.concatenate([hv @ Wr.T + sd[pre + "rgb_linear.bias"], h @ Wa.T + sd[pre + "alpha_linear.bias"]], -1)
         g_rgb, g_alpha = g_out[:, :3], g_out[:, 3:4]
         grads[pre + "rgb_linear.weight"], grads[pre + "rgb_linear.bias"] = g_rgb.T @ hv, g_rgb.sum(0)
-        g_hv = (g_rgb @ Wr) * (hv > 0)
+        g_hv = (g_rgb @ Wr) * (masks["hv"] if masks is not None else (hv > 0))
         grads[pre + "views_linears.0.weight"], grads[pre + "views_linears.0.bias"] = g_hv.T @ hv_in, g_hv.sum(0)
         g_feat = (g_hv @ Wv)[:, :self.W]
         grads[pre + "feature_linear.weight"], grads[pre + "feature_linear.bias"] = g_feat.T @ h, g_feat.sum(0)
@@ -215,7 +218,7 @@ class Net:
             hin, y = acts[i]
             if i in self.skips:
                 g_h = g_h[:, self.input_ch:]
-            g_y = g_h * (y > 0)
+            g_y = g_h * (masks["trunk"][i] if masks is not None else (y > 0))
             grads[f"{pre}pts_linears.{i}.weight"], grads[f"{pre}pts_linears.{i}.bias"] = g_y.T @ hin, g_y.sum(0)
             g_h = g_y @ sd[f"{pre}pts_linears.{i}.weight"].astype(np.float64)
         return out.astype(np.float32), grads

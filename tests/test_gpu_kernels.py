@@ -239,3 +239,77 @@ def test_unsupported_shapes_fail_loudly(ops):
         _packed(ops, sd, W=100, D=2, skips=())
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ops.sample_coarse(torch.zeros(4, 8), 8)
+
+
+# ------------------------------------------------------------------ K3b (training forward + backward)
+def _grad_check(ops, sd, pts, dirs, S, g_out, **kw):
+    cfg = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=(4,), use_viewdirs=True)
+    cfg.update(kw)
+    net = _packed(ops, sd, **kw)
+    raw_ref = net.query(dev(pts), dev(dirs) if dirs is not None else None, pts_per_ray=S)
+    raw, acts = net.query_train(dev(pts), dev(dirs) if dirs is not None else None, pts_per_ray=S)
+    assert torch.equal(raw, raw_ref), "training-mode forward must equal the inference forward bit for bit"
+    grads = net.query_bwd(dev(g_out), pts.shape[0], acts)
+    onet = orc.Net(sd, **cfg)
+    e = orc.embed(pts, 10)
+    if dirs is not None:
+        e = np.concatenate([e, orc.embed(np.repeat(dirs, S, axis=0), 4)], -1)
+    # saved activations: decode the T8 workspace ([4][C][8] per 32-point tile) and check it against the oracle
+    D, W, P = cfg["D"], cfg["W"], pts.shape[0]
+    a = host(acts).reshape(-1, 32 * (64 + 32 + 24 + D * W + W + W // 2))
+
+    def section(off, C):
+        t = a[:, off:off + 32 * C].reshape(-1, 4, C, 8)                 # tile, m, channel, q7
+        return t.transpose(0, 1, 3, 2).reshape(-1, C)[:P]              # [P, C]
+    base = 32 * (64 + 32 + 24)
+    trunk = [section(base + 32 * W * l, W) for l in range(D)]
+    hv = section(base + 32 * W * D + 32 * W, W // 2)
+    x64 = e.astype(np.float64)
+    h = x64[:, :63]
+    for l in range(D):
+        y = np.maximum(h @ sd[f"pts_linears.{l}.weight"].astype(np.float64).T + sd[f"pts_linears.{l}.bias"], 0)
+        np.testing.assert_allclose(trunk[l], y, atol=2e-5 * max(1.0, np.abs(y).max()), rtol=0,
+                                   err_msg=f"saved activation of trunk layer {l}")
+        h = np.concatenate([x64[:, :63], y], -1) if l in cfg["skips"] else y
+    # ReLU gates exactly as the GPU saw them (a pre-activation within rounding of zero may gate differently
+    # in f32 and in the oracle's f64)
+    masks = {"trunk": [t > 0 for t in trunk], "hv": hv > 0}
+    _, ref = onet.forward_backward(e, g_out, masks=masks)
+    for k, g in ref.items():
+        got = host(grads[k]).astype(np.float64)
+        scale = np.abs(g).max() + 1e-30
+        err = np.abs(got - g).max() / scale
+        assert err < 2e-4, (k, err, scale)
+    return grads
+
+
+def test_query_bwd_vs_oracle(ops):
+    rng = np.random.RandomState(7)
+    n_rays, S = 13, 31      # 403 points: ragged last tile
+    pts = rng.uniform(-3, 3, (n_rays * S, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    g_out = rng.normal(size=(n_rays * S, 4)).astype(np.float32)
+    _grad_check(ops, fx.make_nerf_state(31, peaky=True), pts, dirs, S, g_out)
+
+
+@pytest.mark.parametrize("W,D,skips", [(64, 3, (1,)), (128, 4, (2,))])
+def test_query_bwd_shapes(ops, W, D, skips):
+    rng = np.random.RandomState(W)
+    n_rays, S = 9, 50
+    pts = rng.uniform(-3, 3, (n_rays * S, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    g_out = rng.normal(size=(n_rays * S, 4)).astype(np.float32)
+    _grad_check(ops, fx.make_nerf_state(32, D=D, W=W, skips=skips), pts, dirs, S, g_out, D=D, W=W, skips=skips)
+
+
+def test_query_bwd_many_chunks(ops):
+    # > 256 tiles so that chunks hold several tiles each
+    rng = np.random.RandomState(11)
+    n_rays, S = 300, 64
+    pts = rng.uniform(-3, 3, (n_rays * S, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    g_out = (rng.normal(size=(n_rays * S, 4)) * (rng.rand(n_rays * S, 1) < 0.3)).astype(np.float32)
+    _grad_check(ops, fx.make_nerf_state(33), pts, dirs, S, g_out)
