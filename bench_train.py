@@ -1,0 +1,87 @@
+"""bench.py --workload train: BASELINE.json configs[2] -- a 4096-ray training step (64 coarse + 128 fine
+samples, both D=8/W=256 nets): render() forward, img2mse(rgb)+img2mse(rgb0), backward through the
+compositor and both MLPs, (data-parallel: one flat RCCL all-reduce of the gradients), Adam step.
+perturb=1 / raw_noise_std=0 as configs/lego.txt trains.  With N ranks each takes 4096/N rays of the batch."""
+import json
+import os
+import time
+
+import numpy as np
+
+FWD_FLOP_PER_POINT = 1186816
+STEP_FLOP_PER_POINT = 2 * 1744512   # fwd + dgrad + wgrad, SURVEY 8d
+
+
+def run_train(args, torch, dist, world, rank, device):
+    import nerf_fixtures as fx
+    from bench import PEAK_F32_MFMA_TFLOPS, build_nets
+    from nerf_amd import parallel
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render, run_network
+    from nerf_amd.utils import img2mse
+
+    coarse, fine = build_nets(torch, device)
+    params = list(coarse.parameters()) + list(fine.parameters())
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=1., N_importance=128,
+              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
+              raw_noise_std=0., ndc=False, lindisp=False)
+    n_global = 4096
+    ro, rd, target = fx.train_batch(n_global, seed=1)
+    r0, n_local = parallel.slice_partition(n_global, world)[rank]
+    batch_rays = torch.stack([torch.from_numpy(ro[r0:r0 + n_local]), torch.from_numpy(rd[r0:r0 + n_local])]).to(device)
+    target_t = torch.from_numpy(target[r0:r0 + n_local]).to(device)
+    K, _ = fx.intrinsics(400, 400)
+    allreduce = parallel.FlatGradAllReduce(params) if world > 1 else None
+
+    def step():
+        rgb, disp, acc, extras = render(400, 400, K, chunk=32768, rays=batch_rays, retraw=True, near=2., far=6., **kw)
+        opt.zero_grad()
+        # mean over the GLOBAL batch: local mean * (n_local / n_global), summed by the all-reduce
+        loss = (img2mse(rgb, target_t) + img2mse(extras["rgb0"], target_t))
+        loss.backward()
+        if allreduce is not None:
+            allreduce()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        pts = n_global * 256
+        achieved = pts * STEP_FLOP_PER_POINT * args.steps / dt / 1e12
+        out = {
+            "metric": "rays/sec at 64+128 samples/ray (train step)",
+            "value": n_global * args.steps / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "lego-shaped training step, 4096-ray batch, 64+128 samples, D=8 W=256 coarse+fine, "
+                                   "fp32, forward+backward+Adam", "global_batch_rays": n_global,
+                       "parallelism": f"dp{world}, one flat all-reduce (4.77 MB)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "whole step (query_fwd<train> + dgrad + wgrad kernels); algorithmic "
+                                   "3.489 MFLOP/point over wall time"},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

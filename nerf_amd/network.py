@@ -24,7 +24,7 @@ class _QueryFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, key, pts, viewdirs, pts_per_ray, *params):
         packed = module._packed(key)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[5:])   # (grad mode is off inside forward; ask autograd instead)
         if need_grad:
             raw, acts = packed.query_train(pts, viewdirs, pts_per_ray)
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]

@@ -82,6 +82,7 @@ class _CompositeFunction(torch.autograd.Function):
         rgb, disp, acc, weights, depth = ops.composite_fwd(raw, z_vals, rays_d, noise, white_bkgd)
         ctx.save_for_backward(raw, z_vals, rays_d, noise if noise is not None else raw.new_empty(0), disp, acc, depth)
         ctx.white_bkgd = white_bkgd
+        ctx.set_materialize_grads(False)   # unused outputs (disp, acc, weights, depth) arrive as None
         return rgb, disp, acc, weights, depth
 
     @staticmethod

@@ -1,0 +1,114 @@
+"""Training step on the GPU (train.py:226-243: render -> img2mse(rgb)+img2mse(rgb0) -> backward) against
+the gradients the reference's autograd produced (tests/golden/static.npz, `train_*`)."""
+import numpy as np
+import pytest
+import torch
+
+import nerf_fixtures as fx
+from conftest import assert_mostly_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def grad_summary(g):
+    g = g.detach().double().cpu().numpy().reshape(-1)
+    idx = np.linspace(0, g.size - 1, min(256, g.size)).astype(np.int64)
+    return np.concatenate([[g.sum(), np.sqrt((g * g).sum())], g[idx]])
+
+
+def make_nets():
+    from nerf_amd.network import NeRF
+    nets = []
+    for seed in (21, 22):
+        net = NeRF(8, 256, 63, 27, 5, [4], True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_nerf_state(seed, peaky=True).items()})
+        nets.append(net.cuda())
+    return nets
+
+
+def check_grads(net, gold, tag, tol):
+    for k, p in net.named_parameters():
+        ref = gold[f"train_grad_{tag}_{k}"]
+        assert p.grad is not None, k
+        got = grad_summary(p.grad)
+        scale = max(ref[1], 1e-12)
+        assert abs(got[1] - ref[1]) <= tol * scale, (tag, k, got[1], ref[1])
+        np.testing.assert_allclose(got[2:], ref[2:], atol=tol * scale / np.sqrt(max(1, p.numel() / 64)) + 1e-9,
+                                   rtol=5 * tol, err_msg=f"{tag} {k}")
+
+
+def test_train_step_through_render(gold):
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render, run_network
+    from nerf_amd.utils import img2mse
+    coarse, fine = make_nets()
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
+              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
+              raw_noise_std=0., ndc=False, lindisp=False)
+    K, _ = fx.intrinsics(400, 400)
+    batch_rays = torch.stack([dev(gold["train_ro"]), dev(gold["train_rd"])], 0)
+    target = dev(gold["train_target"])
+    rgb, disp, acc, extras = render(400, 400, K, chunk=32768, rays=batch_rays, retraw=True, near=2., far=6., **kw)
+    assert extras["raw"].shape == (64, 192, 4) and "rgb0" in extras
+    loss = img2mse(rgb, target) + img2mse(extras["rgb0"], target)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), gold["train_loss"][0], rtol=2e-4)
+    np.testing.assert_allclose(extras["rgb0"].detach().cpu().numpy(), gold["train_rgb0"], atol=1e-4, rtol=0)
+    assert_mostly_close(rgb.detach().cpu().numpy(), gold["train_rgb"], what="rgb")
+    check_grads(coarse, gold, "coarse", 2e-3)   # the coarse pass sees exactly the reference's sample positions
+    # fine pass end to end: its own resampled positions (sensitive, see conftest.assert_mostly_close)
+    for k, p in fine.named_parameters():
+        ref = gold[f"train_grad_fine_{k}"]
+        assert abs(grad_summary(p.grad)[1] - ref[1]) <= 5e-2 * max(ref[1], 1e-12), k
+
+
+def test_fine_grads_on_reference_positions(gold):
+    """Same step with the fine pass evaluated at the reference's own merged depths: gradients to 2e-3."""
+    from nerf_amd import ops
+    from nerf_amd.render import raw2outputs
+    coarse, fine = make_nets()
+    ro, rd = dev(gold["train_ro"]), dev(gold["train_rd"])
+    n = ro.shape[0]
+    vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+    rays = torch.cat([ro, rd, torch.full((n, 1), 2., device="cuda"), torch.full((n, 1), 6., device="cuda"), vd], -1)
+    z = dev(gold["train_z_vals"])
+    pts = ops.points(rays, z)
+    raw = fine.query_points(pts.reshape(-1, 3), vd, 192, 10, 4).reshape(n, 192, 4)
+    rgb, _, _, _, _ = raw2outputs(raw, z, rays[:, 3:6], 0, True)
+    loss = torch.mean((rgb - dev(gold["train_target"])) ** 2)
+    loss.backward()
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), gold["train_rgb"], atol=1e-4, rtol=0)
+    check_grads(fine, gold, "fine", 2e-3)
+
+
+def test_adam_step_and_repack(gold):
+    """Two optimizer steps: the packed weight copy must follow the nn.Linear parameters (loss changes)."""
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render, run_network
+    from nerf_amd.utils import img2mse
+    coarse, fine = make_nets()
+    opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=1., N_importance=128,
+              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
+              raw_noise_std=1., ndc=False, lindisp=False)
+    K, _ = fx.intrinsics(400, 400)
+    batch_rays = torch.stack([dev(gold["train_ro"]), dev(gold["train_rd"])], 0)
+    target = dev(gold["train_target"])
+    losses = []
+    for _ in range(3):
+        rgb, _, _, extras = render(400, 400, K, chunk=32768, rays=batch_rays, retraw=True, near=2., far=6., **kw)
+        opt.zero_grad()
+        loss = img2mse(rgb, target) + img2mse(extras["rgb0"], target)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        assert all(torch.isfinite(p.grad).all() for p in coarse.parameters())
+    assert len(set(losses)) == 3
