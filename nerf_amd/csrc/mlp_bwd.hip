@@ -52,34 +52,57 @@ __device__ __forceinline__ void store_head_tile(const TBuf &tb, uint32_t sec, in
     }
 }
 
-// acc = act > 0 ? acc : 0, with act read back from the saved activations
+// acc = act > 0 ? acc : 0, with act read back from the saved activations.  One 32-channel tile (16 loads)
+// is in flight ahead of the tile being gated.
 template <int NT>
 __device__ __forceinline__ void relu_mask_t8(const TBuf &ta, uint32_t sec, f32x16 (&g)[NT]) {
     constexpr int C = 32 * NT;
     const int voff = ((ta.m * C + 4 * ta.h) * 8 + ta.q7) * 4;
     asm volatile("" : "+s"(sec));
+    float aa[16], ab[16];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 16; ++r)
+        aa[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            ta.rsrc, voff, (int)((sec + (8 * (r >> 2) + (r & 3)) * 8) * 4), 0));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                ta.rsrc, voff, (int)((sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0));
-            g[t][r] = a > 0.0f ? g[t][r] : 0.0f;
+    for (int t = 0; t < NT; ++t) {
+        float(&cur)[16] = (t & 1) ? ab : aa;
+        float(&nxt)[16] = (t & 1) ? aa : ab;
+        if (t + 1 < NT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                nxt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    ta.rsrc, voff, (int)((sec + (32 * (t + 1) + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0));
         }
-    __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = cur[r] > 0.0f ? g[t][r] : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-// g[t][r] += vec[channel] * s   (head weight vectors in accumulator order)
+// g[t][r] += vec[channel] * s   (head weight vectors in accumulator order), loads one tile ahead
 template <int NT>
 __device__ __forceinline__ void axpy_head(f32x16 (&g)[NT], const WBuf &wb, uint32_t vec, float s) {
+    asm volatile("" : "+s"(vec));
+    f32x4 va[4], vb[4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int gq = 0; gq < 4; ++gq) va[gq] = wload(wb, wb.h16, (vec + (gq * 2) * 4) * 4);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            f32x4 v = wload(wb, wb.h16, (vec + ((t * 4 + gq) * 2) * 4) * 4);
+    for (int t = 0; t < NT; ++t) {
+        f32x4(&cur)[4] = (t & 1) ? vb : va;
+        f32x4(&nxt)[4] = (t & 1) ? va : vb;
+        if (t + 1 < NT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[t][4 * gq + i] = fmaf(v[i], s, g[t][4 * gq + i]);
+            for (int gq = 0; gq < 4; ++gq) nxt[gq] = wload(wb, wb.h16, (vec + (((t + 1) * 4 + gq) * 2) * 4) * 4);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[t][4 * gq + i] = fmaf(cur[gq][i], s, g[t][4 * gq + i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 struct DgradArgs {
@@ -196,37 +219,47 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
 
     const int64_t t0 = (int64_t)chunk * a.chunk_tiles;
     const int64_t t1 = min(a.ntiles, t0 + a.chunk_tiles);
-    for (int64_t tile = t0; tile < t1; ++tile) {
+    // one step = 8 points (m) of one tile: up to 8 wave loads (1 KiB each) feeding up to 64 MFMAs.
+    // Software pipeline: step i+1's loads are issued before step i's MFMAs (4096 cycles of cover).
+    const int64_t nsteps = (t1 - t0) * 4;
+    f32x4 A[4], B[4], An[4], Bn[4];
+    auto load_step = [&](int64_t step, f32x4(&Ax)[4], f32x4(&Bx)[4]) {
+        const int64_t tile = t0 + (step >> 2);
+        const int m = (int)(step & 3);
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.gbuf) + tile * a.g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
         __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.acts) + tile * a.a_tile + a.a_sec, 0, a.Ca * 32 * 4, 0x00020000);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            f32x4 A[4], B[4];
+        for (int x = 0; x < 4; ++x)
+            if (x < na)
+                Ax[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rg, lane_off, ((m * a.Cg + 32 * (n0 + x)) * 8) * 4, 0));
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-                if (x < na)
-                    A[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rg, lane_off, ((m * a.Cg + 32 * (n0 + x)) * 8) * 4, 0));
+        for (int y = 0; y < 4; ++y)
+            if (y < ka)
+                Bx[y] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rx, lane_off, ((m * a.Ca + 32 * (k0 + y)) * 8) * 4, 0));
+    };
+    if (nsteps > 0) load_step(0, A, B);
+    for (int64_t step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) load_step(step + 1, An, Bn);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
-                if (y < ka)
-                    B[y] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rx, lane_off, ((m * a.Ca + 32 * (k0 + y)) * 8) * 4, 0));
+        for (int x = 0; x < 4; ++x)
+            if (x < na) {
+                bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-                if (x < na) {
-                    bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
+                for (int y = 0; y < 4; ++y)
+                    if (y < ka) {
 #pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        if (y < ka) {
+                        for (int j = 0; j < 4; ++j)
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
+                    }
+            }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
-                        }
-                }
-        }
+        for (int x = 0; x < 4; ++x) { A[x] = An[x]; B[x] = Bn[x]; }
     }
     float *slab = a.slab + (int64_t)chunk * NP * KP;
 #pragma unroll

@@ -279,18 +279,31 @@ __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)
         for (int r = 0; r < 16; ++r) dst[t][r] = fmaxf(src[t][r], lo);
 }
 
-// lane-local part of  sum_c vec[c] * h[c]  over this lane's channels, then the other half's part
+// lane-local part of  sum_c vec[c] * h[c]  over this lane's channels, then the other half's part.
+// Loads are issued a whole tile (4 x 16 B) ahead of their use: left to itself the compiler waits for
+// each load before the next (an L2 round trip per 16 bytes).
 template <int NT_IN>
 __device__ __forceinline__ float head_dot(const f32x16 (&hin)[NT_IN], const WBuf &wb, uint32_t vec) {
     float s = 0.0f;
+    asm volatile("" : "+s"(vec));
+    f32x4 va[4], vb[4];
 #pragma unroll
-    for (int t = 0; t < NT_IN; ++t)
+    for (int g = 0; g < 4; ++g) va[g] = wload(wb, wb.h16, (vec + (g * 2) * 4) * 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = wload(wb, wb.h16, (vec + ((t * 4 + g) * 2) * 4) * 4);
+    for (int t = 0; t < NT_IN; ++t) {
+        f32x4(&cur)[4] = (t & 1) ? vb : va;
+        f32x4(&nxt)[4] = (t & 1) ? va : vb;
+        if (t + 1 < NT_IN) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s = fmaf(v[i], hin[t][4 * g + i], s);
+            for (int g = 0; g < 4; ++g) nxt[g] = wload(wb, wb.h16, (vec + (((t + 1) * 4 + g) * 2) * 4) * 4);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s = fmaf(cur[g][i], hin[t][4 * g + i], s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     return s + __shfl_xor(s, 32);
 }
 

@@ -22,9 +22,10 @@ class _QueryFunction(torch.autograd.Function):
     """raw = net(points); backward produces parameter gradients with the HIP backward kernels."""
 
     @staticmethod
-    def forward(ctx, module, key, pts, viewdirs, pts_per_ray, *params):
+    def forward(ctx, module, key, pts, viewdirs, pts_per_ray, need_grad, *params):
         packed = module._packed(key)
-        need_grad = any(ctx.needs_input_grad[5:])   # (grad mode is off inside forward; ask autograd instead)
+        # need_grad is decided by the caller: inside forward grad mode is always off, and
+        # ctx.needs_input_grad ignores torch.no_grad()
         if need_grad:
             raw, acts = packed.query_train(pts, viewdirs, pts_per_ray)
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
@@ -38,7 +39,7 @@ class _QueryFunction(torch.autograd.Function):
         packed = ctx.module._packed(ctx.key)
         grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts)
         order = [name for name, _ in ctx.module.named_parameters()]
-        return (None, None, None, None, None) + tuple(grads.get(n) for n in order)
+        return (None, None, None, None, None, None) + tuple(grads.get(n) for n in order)
 
 
 class NeRF(nn.Module):
@@ -80,6 +81,9 @@ class NeRF(nn.Module):
         self._packed_cache = {}
         return super()._apply(fn, *args, **kwargs)
 
+    def _need_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def _params_in_order(self):
         return [p for _, p in self.named_parameters()]
 
@@ -87,14 +91,14 @@ class NeRF(nn.Module):
     def forward(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, *self._params_in_order())
+        out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, self._need_grad(), *self._params_in_order())
         return out.reshape(*lead, out.shape[-1])
 
     def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
         """pts [P,3]; viewdirs [P/pts_per_ray, 3] or None -> raw [P, 4|output_ch] (render.py:31-56 fused)."""
         key = (0, multires, multires_views if self.use_viewdirs else 0)
         return _QueryFunction.apply(self, key, pts, viewdirs if self.use_viewdirs else None, pts_per_ray,
-                                    *self._params_in_order())
+                                    self._need_grad(), *self._params_in_order())
 
     # ------------------------------------------------------------------ Keras import (network.py:71-99)
     def load_weights_from_keras(self, weights):

@@ -1,0 +1,74 @@
+"""Multi-process paths on CPU (gloo, world_size 2): the row-sharded render gather and the flat gradient
+all-reduce of nerf_amd.parallel are placement logic around torch.distributed; the kernels themselves are
+covered by the GPU tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # a deterministic stand-in for "render these rows": value = f(row, col)
+        def rows(row0, nrows):
+            r = torch.arange(row0, row0 + nrows, dtype=torch.float32)[:, None, None]
+            c = torch.arange(W, dtype=torch.float32)[None, :, None]
+            ch = torch.arange(5, dtype=torch.float32)[None, None, :]
+            return (r * 1000 + c + ch / 10).reshape(-1, 5)
+        img = parallel.render_sharded(rows, H, W, rank, world)
+        # data-parallel gradient averaging
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(7, 3)), torch.nn.Parameter(torch.zeros(5)),
+                  torch.nn.Parameter(torch.zeros(2, 2))]
+        params[0].grad = torch.full((7, 3), float(rank + 1))
+        params[1].grad = torch.arange(5, dtype=torch.float32) * (rank + 1)
+        params[2].grad = None          # a parameter that got no gradient on this rank
+        parallel.FlatGradAllReduce(params)()
+        if rank == 0:
+            out["img"] = img.numpy()
+            out["g0"] = params[0].grad.numpy().copy()
+            out["g1"] = params[1].grad.numpy().copy()
+            out["g2"] = params[2].grad.numpy().copy()
+        else:
+            assert img is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W", [(8, 6), (7, 5)])
+def test_render_sharded_and_grad_allreduce(H, W):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), H, W, out), nprocs=world, join=True)
+    r = np.arange(H, dtype=np.float32)[:, None, None]
+    c = np.arange(W, dtype=np.float32)[None, :, None]
+    ch = np.arange(5, dtype=np.float32)[None, None, :]
+    np.testing.assert_array_equal(out["img"], r * 1000 + c + ch / 10)      # bit-identical to the 1-rank image
+    np.testing.assert_allclose(out["g0"], np.full((7, 3), 1.5))
+    np.testing.assert_allclose(out["g1"], np.arange(5) * 1.5)
+    np.testing.assert_allclose(out["g2"], 0.0)
+
+
+def test_partitions():
+    assert parallel.row_partition(800, 8) == [(100 * i, 100) for i in range(8)]
+    assert parallel.row_partition(7, 2) == [(0, 4), (4, 3)]
+    parts = parallel.slice_partition(4096, 3)
+    assert sum(n for _, n in parts) == 4096 and parts[0][0] == 0
+    assert all(a[0] + a[1] == b[0] for a, b in zip(parts, parts[1:]))
