@@ -105,6 +105,26 @@ int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *pac
                   const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                   void *stream);
 
+/* ---- D-NeRF deformation chain (vanilla_dynamic/) ----
+ * The time ("deformation") net of DNeRF_Deformation (vanilla_dynamic/network.py:254-305) is described with
+ * nrf_net_t as: pts_w/pts_b = the `_time` layers, out_w/out_b = `_time_out` (W -> 3), input_ch = position
+ * channels, input_ch_views = TIME channels (layer 0 reads input_ch + time channels), use_viewdirs = 0,
+ * skips_mask as the canonical net (network.py:245).  emb->multires_time = L of get_time_embedder. */
+int64_t nrf_dnerf_time_packed_floats(const nrf_net_t *time_net, const nrf_embed_t *emb);
+int nrf_dnerf_pack_time_weights(const nrf_net_t *time_net, const nrf_embed_t *emb, float *packed, void *stream);
+
+/* K6  fused deformation query -- vanilla_dynamic/render.py:49-124 (run_network_dnerf) +
+ * vanilla_dynamic/network.py:307-341 (DNeRF_Deformation.forward):  dx = time_net(gamma(x), gamma(t));
+ * raw = occ_net(gamma(x + dx), gamma(d)).  pts [P,3]; viewdirs [P/pts_per_ray, 3]; times [P/pts_per_ray]
+ * (one per ray) or [P] when times_per_point != 0; raw [P,4]; dx [P,3].  packed_occ from
+ * nrf_mlp_pack_weights(occ_net), packed_time from nrf_dnerf_pack_time_weights.  `netchunk` and
+ * `zero_canonical` reproduce the reference's per-netchunk "t == 0 -> skip the time net" decision
+ * (network.py:315-322, taken from the first point of each chunk of `netchunk` points). */
+int nrf_dnerf_query_fwd(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                        const float *packed_time, const float *packed_occ, const float *pts, const float *viewdirs,
+                        const float *times, int64_t n_points, int32_t pts_per_ray, int32_t times_per_point,
+                        int64_t netchunk, int32_t zero_canonical, float *raw, float *dx, void *stream);
+
 /* K4  raw2outputs -- render.py:82-131.  raw [N,S,4], z_vals [N,S], rays_d rows of `d_stride` floats
  * (pass rays+3 with d_stride = ncol to read directions out of the ray matrix), noise NULL or [N,S]
  * (already multiplied by raw_noise_std).  Outputs rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]. */

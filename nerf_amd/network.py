@@ -81,8 +81,14 @@ class NeRF(nn.Module):
         self._packed_cache = {}
         return super()._apply(fn, *args, **kwargs)
 
-    def _need_grad(self):
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+    def _need_grad(self, x=None):
+        if not torch.is_grad_enabled():
+            return False
+        if x is not None and x.requires_grad:
+            # the backward kernels produce PARAMETER gradients only; refusing beats silently dropping d/dx
+            raise NotImplementedError("nerf_amd: gradients w.r.t. the network INPUT are not built (only parameter "
+                                      "gradients); detach the input or run under torch.no_grad()")
+        return any(p.requires_grad for p in self.parameters())
 
     def _params_in_order(self):
         return [p for _, p in self.named_parameters()]
@@ -91,14 +97,14 @@ class NeRF(nn.Module):
     def forward(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, self._need_grad(), *self._params_in_order())
+        out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, self._need_grad(x2), *self._params_in_order())
         return out.reshape(*lead, out.shape[-1])
 
     def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
         """pts [P,3]; viewdirs [P/pts_per_ray, 3] or None -> raw [P, 4|output_ch] (render.py:31-56 fused)."""
         key = (0, multires, multires_views if self.use_viewdirs else 0)
         return _QueryFunction.apply(self, key, pts, viewdirs if self.use_viewdirs else None, pts_per_ray,
-                                    self._need_grad(), *self._params_in_order())
+                                    self._need_grad(pts), *self._params_in_order())
 
     # ------------------------------------------------------------------ Keras import (network.py:71-99)
     def load_weights_from_keras(self, weights):

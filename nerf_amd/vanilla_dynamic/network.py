@@ -1,0 +1,237 @@
+"""D-NeRF networks -- counterpart of vanilla_dynamic/network.py.
+
+  NeRF                   :13-97    canonical net; forward(x, ts=None) -> (out, zeros[P,3]); optional LayerNorm
+  DNeRF_Straightforward  :100-196  one net on cat[gamma(x), gamma(t)]
+  DNeRF_Deformation      :199-341  time net -> dx -> gamma(x + dx) -> canonical net
+
+State_dict keys are the reference's (`_occ.*`, `_time.{i}.*`, `_time_out.*`, `pts_layernorms.*`, ...).
+DNeRF_Deformation runs as ONE fused HIP kernel (nrf_dnerf_query_fwd) whenever the inputs allow it: raw
+points / raw time available (run_network_dnerf always passes them), standard embedders, no LayerNorm.
+Training through the deformation chain is not built yet in this round: calls that need gradients raise.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib, ops
+from ..network import NeRF as _StaticNeRF
+
+
+class NeRF(_StaticNeRF):
+    """Canonical net: the static NeRF plus the (out, zeros) return convention and optional LayerNorm."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
+                 use_layernorm=False):
+        super().__init__(D=D, W=W, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=output_ch,
+                         skips=skips, use_viewdirs=use_viewdirs)
+        self.use_layernorm = use_layernorm
+        if use_layernorm:
+            self.pts_layernorms = nn.ModuleList([nn.LayerNorm(W) for _ in range(D)])
+            self.views_layernorm = nn.LayerNorm(W // 2)
+
+    def _packed(self, key):
+        pk = self._packed_cache.get(key)
+        if pk is None:
+            params = {k: v for k, v in self.named_parameters() if "layernorm" not in k}
+            if not self.use_viewdirs:
+                params = {k: v for k, v in params.items() if not k.startswith("views_linears")}
+            mode, L, Lv = key
+            pk = ops.PackedNet(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
+                               list(self.skips), self.use_viewdirs, mode=mode, multires=L, multires_views=Lv)
+            self._packed_cache[key] = pk
+        return pk
+
+    def forward(self, x, ts=None):
+        if self.use_layernorm:
+            out = self._forward_layernorm(x)
+        else:
+            out = super().forward(x)
+        return out, torch.zeros_like(x[:, :3])
+
+    def _forward_layernorm(self, x):
+        # LayerNorm variant (network.py:46-48, :75-76, :88-89): plain torch ops on the GPU -- the fused
+        # kernels have no normalisation stage.
+        input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = input_pts
+        for i in range(self.D):
+            h = F.relu(self.pts_layernorms[i](self.pts_linears[i](h)))
+            if i in self.skips:
+                h = torch.cat([input_pts, h], -1)
+        if not self.use_viewdirs:
+            return self.output_linear(h)
+        alpha = self.alpha_linear(h)
+        h = torch.cat([self.feature_linear(h), input_views], -1)
+        h = F.relu(self.views_layernorm(self.views_linears[0](h)))
+        return torch.cat([self.rgb_linear(h), alpha], -1)
+
+
+class DNeRF_Straightforward(nn.Module):
+    """cat[gamma(x), gamma(t)] -> NeRF-shaped MLP (network.py:100-196).  NB: at the reference's HEAD this
+    network type cannot be rendered (run_network_dnerf passes pts_raw=/t_raw= which this forward does not
+    accept); the class is kept for construction / checkpoint parity and evaluates with torch ops."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, input_ch_time=1, output_ch=4, skips=[4],
+                 use_viewdirs=True):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views, self.input_ch_time = input_ch, input_ch_views, input_ch_time
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        in0 = input_ch + input_ch_time
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(in0, W)] + [nn.Linear(W + in0 if i in skips else W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+    def forward(self, x, ts):
+        t_embed = ts[0] if isinstance(ts, (list, tuple)) else ts
+        input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        xt = torch.cat([input_pts, t_embed], dim=-1)
+        h = xt
+        for i in range(self.D):
+            h = F.relu(self.pts_linears[i](h))
+            if i in self.skips:
+                h = torch.cat([xt, h], -1)
+        if self.use_viewdirs:
+            alpha = self.alpha_linear(h)
+            h = torch.cat([self.feature_linear(h), input_views], -1)
+            h = F.relu(self.views_linears[0](h))
+            out = torch.cat([self.rgb_linear(h), alpha], -1)
+        else:
+            out = self.output_linear(h)
+        return out, torch.zeros_like(input_pts[:, :3])
+
+
+class DNeRF_Deformation(nn.Module):
+    def __init__(self, D=8, W=256, D_deform=8, W_deform=256, input_ch=3, input_ch_views=3, input_ch_time=1,
+                 output_ch=4, skips=[4], skips_deform=[4], use_viewdirs=True, zero_canonical=True,
+                 use_layernorm=False):
+        super().__init__()
+        self.D, self.W = D, W
+        self.D_deform, self.W_deform = D_deform, W_deform
+        self.input_ch, self.input_ch_views, self.input_ch_time = input_ch, input_ch_views, input_ch_time
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        self.zero_canonical, self.use_layernorm = zero_canonical, use_layernorm
+        self.embed_fn = None
+        self._occ = NeRF(D=D, W=W, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=output_ch,
+                         skips=skips, use_viewdirs=use_viewdirs, use_layernorm=use_layernorm)
+        self.skips_deform = skips   # the `skips_deform` argument is ignored, as in the reference (network.py:245)
+        widths = [input_ch + input_ch_time] + [W_deform + input_ch if i in self.skips_deform else W_deform
+                                               for i in range(D_deform - 1)]
+        self._time = nn.ModuleList([nn.Linear(w_in, W_deform) for w_in in widths])
+        self._time_out = nn.Linear(W_deform, 3)
+        self._time_layernorms = nn.ModuleList([nn.LayerNorm(W_deform) for _ in range(D_deform)]) \
+            if use_layernorm else None
+        self._packed_time = None
+        self._time_versions = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed_time = None
+        return super()._apply(fn, *args, **kwargs)
+
+    # ------------------------------------------------------------------ fused path
+    def _time_desc(self, L, Lt):
+        n = _lib.NrfNet()
+        n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch, n.use_viewdirs = \
+            self.D_deform, self.W_deform, self.input_ch, self.input_ch_time, 3, 0
+        n.skips_mask = sum(1 << int(s) for s in self.skips_deform)
+        return n, _lib.NrfEmbed(0, L, 0, Lt)
+
+    def _refresh_time(self, L, Lt):
+        params = [p for l in self._time for p in (l.weight, l.bias)] + [self._time_out.weight, self._time_out.bias]
+        vers = (L, Lt) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed_time is not None and vers == self._time_versions:
+            return
+        n, e = self._time_desc(L, Lt)
+        self._tkeep = [ops._f32(p.detach(), "time-net parameter") for p in params]
+        for i in range(self.D_deform):
+            n.pts_w[i] = C.c_void_p(self._tkeep[2 * i].data_ptr())
+            n.pts_b[i] = C.c_void_p(self._tkeep[2 * i + 1].data_ptr())
+        n.out_w, n.out_b = C.c_void_p(self._tkeep[-2].data_ptr()), C.c_void_p(self._tkeep[-1].data_ptr())
+        lib = _lib.lib()
+        nfl = lib.nrf_dnerf_time_packed_floats(C.byref(n), C.byref(e))
+        if nfl <= 0:
+            raise RuntimeError("nrf_dnerf_time_packed_floats: " + lib.nrf_last_error_string().decode())
+        if self._packed_time is None or self._packed_time.numel() != nfl:
+            self._packed_time = torch.empty((nfl,), device=self._tkeep[0].device, dtype=torch.float32)
+        _lib.check(lib.nrf_dnerf_pack_time_weights(C.byref(n), C.byref(e), ops._ptr(self._packed_time), ops._stream()),
+                   "nrf_dnerf_pack_time_weights")
+        self._time_versions = vers
+
+    def query_points(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires, multires_views,
+                     multires_time):
+        """Fused deformation chain on raw inputs: pts [P,3], viewdirs [P/pts_per_ray,3], times [P] or
+        [P/pts_per_ray] -> (raw [P,4], dx [P,3])."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("nerf_amd: training through the D-NeRF deformation chain is not built yet "
+                                      "(run under torch.no_grad() to render)")
+        if self.use_layernorm or not self.use_viewdirs:
+            raise RuntimeError("nerf_amd: the fused deformation kernel needs use_viewdirs=True, use_layernorm=False")
+        self._refresh_time(multires, multires_time)
+        occ = self._occ._packed((0, multires, multires_views))
+        occ.refresh()
+        tn, e = self._time_desc(multires, multires_time)
+        e.multires_views = multires_views
+        pts, viewdirs = ops._f32(pts, "pts"), ops._f32(viewdirs, "viewdirs")
+        times = ops._f32(times, "times").reshape(-1)
+        P = pts.shape[0]
+        raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
+        dx = torch.empty((P, 3), device=pts.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nrf_dnerf_query_fwd(
+            C.byref(tn), C.byref(occ.net), C.byref(e), ops._ptr(self._packed_time), ops._ptr(occ.packed),
+            ops._ptr(pts), ops._ptr(viewdirs), ops._ptr(times), P, int(pts_per_ray), int(bool(times_per_point)),
+            int(netchunk), int(bool(self.zero_canonical)), ops._ptr(raw), ops._ptr(dx), ops._stream()),
+            "nrf_dnerf_query_fwd")
+        return raw, dx
+
+    # ------------------------------------------------------------------ reference-shaped forward
+    def _fusable_forward(self, x, pts_raw, t_raw):
+        from ..positional_encoding import _EmbedFn
+        ef = self.embed_fn
+        return (pts_raw is not None and t_raw is not None and isinstance(ef, _EmbedFn) and ef.fusable
+                and ef.out_dim == self.input_ch and not self.use_layernorm and self.use_viewdirs
+                and (self.input_ch_views - 3) % 6 == 0 and (self.input_ch_time - 1) % 2 == 0
+                and (self.input_ch_views - 3) // 6 <= 4 and (self.input_ch_time - 1) // 2 <= 10
+                and x.is_cuda)
+
+    def forward(self, x, ts, pts_raw=None, t_raw=None):
+        """x [P, input_ch + input_ch_views] embedded; ts embedded time (or [t, t]); returns (out, dx)."""
+        if self._fusable_forward(x, pts_raw, t_raw):
+            # the direction embedding starts with the raw direction (include_input): x[:, input_ch : input_ch+3]
+            dirs = x[:, self.input_ch:self.input_ch + 3]
+            P = x.shape[0]
+            return self.query_points(pts_raw, dirs, t_raw, 1, True, max(P, 1), self.embed_fn.multires,
+                                     (self.input_ch_views - 3) // 6, (self.input_ch_time - 1) // 2)
+        return self._forward_torch(x, ts, pts_raw, t_raw)
+
+    def _forward_torch(self, x, ts, pts_raw, t_raw):
+        # generic composition for configurations the fused kernel does not cover (LayerNorm, exotic embedders)
+        input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        t = ts[0] if isinstance(ts, (list, tuple)) else ts
+        probe = t_raw if t_raw is not None else t
+        cur_time = probe[0, 0].item() if probe.numel() > 0 else 1.0
+        if cur_time == 0.0 and self.zero_canonical:
+            dx = torch.zeros(input_pts.shape[0], 3, device=input_pts.device)
+            canonical_input = torch.cat([input_pts, input_views], dim=-1)
+        else:
+            h = torch.cat([input_pts, t], dim=-1)
+            for i in range(self.D_deform):
+                h = self._time[i](h)
+                if self._time_layernorms is not None:
+                    h = self._time_layernorms[i](h)
+                h = F.relu(h)
+                if i in self.skips_deform:
+                    h = torch.cat([input_pts, h], -1)
+            dx = self._time_out(h)
+            base = pts_raw if pts_raw is not None else input_pts[:, :3]
+            if self.embed_fn is None:
+                raise RuntimeError("embed_fn must be set for deformation network")
+            canonical_input = torch.cat([self.embed_fn(base + dx), input_views], dim=-1)
+        out, _ = self._occ(canonical_input, t)
+        return out, dx

@@ -1,0 +1,174 @@
+"""D-NeRF deformation chain on the GPU (kernel K6) through nerf_amd.vanilla_dynamic,
+against golden vectors produced by the reference's vanilla_dynamic package (tests/golden/dnerf.npz) and the
+C oracle.  Same bars as the static path: 1e-4 max-abs where the sample positions are identical (coarse pass,
+direct queries); the fine pass end to end inherits sample_pdf's sensitivity (conftest.assert_mostly_close) --
+more so here, because the fixture's deformation net is scaled up (dx_scale=3) to make dx matter."""
+import numpy as np
+import pytest
+import torch
+
+import nerf_fixtures as fx
+from conftest import assert_mostly_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def parts():
+    import nerf_amd.vanilla_dynamic as vd
+    embed_fn, ich = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, ichv = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, icht = vd.get_time_embedder(10)
+    assert (ich, ichv, icht) == (63, 27, 21)
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                 input_ch_time=21, output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    sd = fx.make_dnerf_state(31, peaky=True, dx_scale=3.0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    qfn = lambda inputs, viewdirs, times, fn: vd.run_network_dnerf(  # noqa: E731
+        inputs, viewdirs, times, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, embed_time_fn=embed_time,
+        netchunk=65536, network_type="deformation")
+    return vd, model, qfn, (embed_fn, embeddirs_fn, embed_time), sd
+
+
+def test_embedders(gold_dnerf, parts):
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    G = gold_dnerf
+    np.testing.assert_allclose(host(embed_time(dev(G["time_x"]))), G["time_pe"], atol=3e-7, rtol=0)
+    e_noinp, d = vd.get_embedder(4, 0, input_dims=3, include_input=False)
+    assert d == 24
+    np.testing.assert_allclose(host(e_noinp(dev(G["pe_noinp_x"]))), G["pe_noinp"], atol=3e-7, rtol=0)
+    ident, d = vd.get_time_embedder(0)
+    assert d == 1
+
+
+@pytest.mark.parametrize("name,tval", [("t0", 0.0), ("t05", 0.5)])
+def test_forward_reference_call_shape(gold_dnerf, parts, name, tval):
+    """model(x_embedded, [te, te], pts_raw=, t_raw=) exactly as run_network_dnerf calls it (render.py:112)."""
+    _, model, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    G = gold_dnerf
+    pts, dirs = dev(G["fwd_pts"]), dev(G["fwd_dirs"])
+    with torch.no_grad():
+        xin = torch.cat([embed_fn(pts), embeddirs_fn(dirs)], -1)
+        t_raw = torch.full((256, 1), tval, device="cuda")
+        te = embed_time(t_raw)
+        out, dx = model(xin, [te, te], pts_raw=pts, t_raw=t_raw)
+    ref_out, ref_dx = G[f"fwd_{name}_out"], G[f"fwd_{name}_dx"]
+    np.testing.assert_allclose(host(dx), ref_dx, atol=2e-5 * max(1.0, np.abs(ref_dx).max()), rtol=0)
+    # dx feeds a frequency-512 encoding: |d out| <= 512 * |d dx| * gain; compare with a matching bar
+    np.testing.assert_allclose(host(out), ref_out, atol=2e-3 * np.abs(ref_out).max(), rtol=0)
+    if tval == 0.0:
+        assert float(dx.abs().max()) == 0.0
+        np.testing.assert_allclose(host(out), ref_out, atol=2e-5 * np.abs(ref_out).max(), rtol=0)
+
+
+def test_forward_vs_oracle(gold_dnerf, parts):
+    """Same query against the C oracle fed the GPU's own dx-path inputs: tight agreement of dx, and of raw
+    given the deformed points."""
+    import oracle.oracle as orc
+    _, model, qfn, _, sd = parts
+    G = gold_dnerf
+    pts, dirs = G["fwd_pts"], G["fwd_dirs"]
+    with torch.no_grad():
+        raw, dx = qfn(dev(pts).reshape(4, 64, 3), dev(dirs[:4]), torch.full((4, 1), 0.5, device="cuda"), model)
+    o_raw, o_dx = orc.run_network_dnerf(pts.reshape(4, 64, 3), dirs[:4], np.full((4, 1), 0.5, np.float32),
+                                        orc.Net(sd, prefix="_occ."), orc.TimeNet(sd))
+    np.testing.assert_allclose(host(dx), o_dx, atol=2e-5 * max(1.0, np.abs(o_dx).max()), rtol=0)
+    np.testing.assert_allclose(host(raw), o_raw, atol=2e-3 * np.abs(o_raw).max(), rtol=0)
+
+
+def test_canonical_net_alone(gold_dnerf, parts):
+    _, model, _, (embed_fn, embeddirs_fn, _), _ = parts
+    G = gold_dnerf
+    with torch.no_grad():
+        xin = torch.cat([embed_fn(dev(G["fwd_pts"])), embeddirs_fn(dev(G["fwd_dirs"]))], -1)
+        o, z = model._occ(xin)
+    np.testing.assert_allclose(host(o), G["occ_out"], atol=2e-5 * np.abs(G["occ_out"]).max(), rtol=0)
+    assert z.shape == (256, 3) and float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["t0", "t05", "tvar"])
+def test_render_rays_dnerf(gold_dnerf, parts, name):
+    vd, model, qfn, _, _ = parts
+    G = gold_dnerf
+    rays = dev(G["rr_rays"])
+    tv = dev(G["rr_tvar_times"]) if name == "tvar" else torch.full((48, 1), {"t0": 0.0, "t05": 0.5}[name],
+                                                                   device="cuda")
+    with torch.no_grad():
+        ret = vd.render_rays_dnerf(rays, tv, model, qfn, 64, retraw=(name != "tvar"), perturb=0., N_importance=128,
+                                   network_fine=None, white_bkgd=True)
+    want = {"rgb_map", "disp_map", "acc_map", "dx", "rgb0", "disp0", "acc0", "dx0", "z_std"}
+    assert set(ret) == want | ({"raw"} if name != "tvar" else set())
+    # coarse pass: identical sample positions
+    ref_dx0 = G[f"rr_{name}_dx0"]
+    np.testing.assert_allclose(host(ret["dx0"]), ref_dx0, atol=2e-5 * max(1.0, np.abs(ref_dx0).max()), rtol=0)
+    tol0 = 1e-4 if name == "t0" else 2e-3     # dx error x frequency-512 encoding x peaky sigma head
+    np.testing.assert_allclose(host(ret["rgb0"]), G[f"rr_{name}_rgb0"], atol=tol0, rtol=0)
+    np.testing.assert_allclose(host(ret["acc0"]), G[f"rr_{name}_acc0"], atol=tol0, rtol=0)
+    for k in ("rgb_map", "acc_map", "z_std"):
+        assert_mostly_close(host(ret[k]), G[f"rr_{name}_{k}"], what=f"{name} {k}", atol=1e-3, frac=0.7, hard=0.5)
+    assert ret["dx"].shape == (48, 192, 3)
+
+
+def test_render_dnerf_from_pose(gold_dnerf, parts):
+    vd, model, qfn, _, _ = parts
+    G = gold_dnerf
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+              white_bkgd=True, raw_noise_std=0.)
+    with torch.no_grad():
+        rgb, disp, acc, extras = vd.render_dnerf(8, 8, G["render_K"], 0.25, chunk=40, c2w=dev(G["render_c2w"]),
+                                                 near=2., far=6., use_viewdirs=True, **kw)
+        rgb2, _, _, _ = vd.render_dnerf(8, 8, G["render_K"], torch.full((64,), 0.25), chunk=1 << 15,
+                                        c2w=dev(G["render_c2w"]), near=2., far=6., use_viewdirs=True, **kw)
+    assert rgb.shape == (8, 8, 3) and disp.shape == (8, 8) and extras["dx"].shape == (8, 8, 192, 3)
+    assert torch.equal(rgb, rgb2)      # chunking and scalar-vs-tensor time do not change the result
+    assert_mostly_close(host(rgb), G["render_rgb"], what="rgb", atol=1e-3, frac=0.7, hard=0.5)
+    assert_mostly_close(host(acc), G["render_acc"], what="acc", atol=1e-3, frac=0.7, hard=0.5)
+
+
+def test_netchunk_t0_quirk(parts):
+    """network.py:315-322: the t == 0 shortcut is decided per netchunk from the chunk's FIRST point.  With
+    per-ray times [0, 0.5] and netchunk = one ray's samples the first ray skips the time net, the second does
+    not; with one big chunk (first point has t == 0) both skip it."""
+    vd, model, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    rng = np.random.RandomState(0)
+    pts = dev(rng.uniform(-1, 1, (2, 64, 3)))
+    dirs = dev(fx.blender_rays(2, 1)[:, -3:])
+    times = dev(np.array([[0.0], [0.5]]))
+    run = lambda nc: vd.run_network_dnerf(pts, dirs, times, model, embed_fn, embeddirs_fn, embed_time, netchunk=nc)  # noqa: E731
+    with torch.no_grad():
+        raw_a, dx_a = run(64)
+        raw_b, dx_b = run(1 << 16)
+    assert float(dx_a[0].abs().max()) == 0.0 and float(dx_a[1].abs().max()) > 0.0
+    assert float(dx_b.abs().max()) == 0.0
+    assert torch.equal(raw_a[0], raw_b[0]) and not torch.equal(raw_a[1], raw_b[1])
+
+
+def test_training_raises_until_built(parts):
+    vd, model, qfn, _, _ = parts
+    rays = dev(fx.blender_rays(4, 2))
+    with pytest.raises(NotImplementedError):
+        vd.render_rays_dnerf(rays, torch.full((4, 1), 0.5, device="cuda"), model, qfn, 64, N_importance=0)
+
+
+def test_layernorm_variant_runs(parts):
+    """use_layernorm=True has no fused kernel: composed from torch ops + the same reference-keyed parameters."""
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    m = vd.DNeRF_Deformation(D=2, W=64, D_deform=2, W_deform=64, input_ch=63, input_ch_views=27, input_ch_time=21,
+                             skips=[4], use_layernorm=True).cuda()
+    m.embed_fn = embed_fn
+    assert "_occ.pts_layernorms.0.weight" in m.state_dict() and "_time_layernorms.1.bias" in m.state_dict()
+    pts = dev(np.random.RandomState(1).uniform(-1, 1, (3, 8, 3)))
+    with torch.no_grad():
+        raw, dx = vd.run_network_dnerf(pts, dev(fx.blender_rays(3, 1)[:, -3:]), torch.full((3, 1), 0.3, device="cuda"),
+                                       m, embed_fn, embeddirs_fn, embed_time)
+    assert raw.shape == (3, 8, 4) and dx.shape == (3, 8, 3) and torch.isfinite(raw).all()
