@@ -223,6 +223,7 @@ __device__ __forceinline__ float wload1(const WBuf &wb, uint32_t soff_bytes) {
 // `b` etc. below are offsets in FLOATS from the start of the packed buffer (wave-uniform).
 template <int NT_OUT>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT_OUT], const WBuf &wb, uint32_t b) {
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay between the neighbouring stages (hoisted, they spill)
 #pragma unroll
     for (int t = 0; t < NT_OUT; ++t)
 #pragma unroll

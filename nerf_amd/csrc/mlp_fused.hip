@@ -86,10 +86,12 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 const float alpha = head_dot<NT>(hin, wb, (uint32_t)pl.alpha_vec) + wload1(wb, (uint32_t)pl.alpha_b * 4);
                 load_bias<NT>(acc, wb, (uint32_t)pl.feat_b);                                     // network.py:57
                 gemm_hid<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w);
-                if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_feat, acc);
+                // the feature vector becomes an MFMA operand: move it out of the accumulator file (no ReLU)
+                relu_move<NT>(hin, acc, false);
+                if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_feat, hin);
                 f32x16 acc2[NT / 2];
                 load_bias<NT / 2>(acc2, wb, (uint32_t)pl.views_b);                               // network.py:58-62
-                gemm_hid<NT, NT / 2>(acc2, acc, wb, (uint32_t)pl.views_w_hid);
+                gemm_hid<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid);
                 gemm_in<kKsD, NT / 2>(acc2, din, wb, (uint32_t)pl.views_w_in);
                 relu_move<NT / 2>(acc2, acc2, true);
                 if constexpr (TRAIN) store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): kernel-trace stats + separate PMC passes for the render and train
+# benches.  Outputs land under gpurun_out/prof_<tag>/; summaries are copied into profiles/ by hand.
+#   bash scripts/profile_gpu.sh <tag> [stats|pmc|sq|list] ...
+set -e -o pipefail
+TAG=${1:?tag}; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+RENDER="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+TRAIN="$ROOT/bench.py --workload train --steps 5 --warmup 2"
+for what in "$@"; do
+  case $what in
+    list)
+      timeout -s KILL 60 rocprofv3 -L > "$OUT/counters.txt" 2>&1 || true ;;
+    stats)
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render" -o render -- python3 $RENDER > "$OUT/render_stats.log" 2>&1
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN > "$OUT/train_stats.log" 2>&1 ;;
+    pmc)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_$c" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_render_$c.log" 2>&1
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_train_$c" -o train -- python3 $ROOT/bench.py --workload train --steps 1 --warmup 1 > "$OUT/pmc_train_$c.log" 2>&1
+      done ;;
+    sq)
+      timeout -s KILL 240 rocprofv3 --pmc $SQ_COUNTERS --output-format csv -d "$OUT/pmc_render_sq" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_render_sq.log" 2>&1 ;;
+  esac
+done
+for d in "$OUT"/pmc_*/; do [ -d "$d" ] && python3 $ROOT/scripts/pmc_summary.py "$d" > "${d%/}.summary.json"; done
+find "$OUT" \( -name '*.db' -o -name '*_trace.csv' -o -name '*counter_collection.csv' \) -size +2M -delete   # keep the merge-back small
+ls -R "$OUT" | head -60
