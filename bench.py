@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- rays/sec of the NeRF per-ray rendering path at 64 coarse + 128 fine samples per ray.
 
-    python bench.py --gpus N --steps K --warmup W [--workload render|train] [--size 800]
+    python bench.py --gpus N --steps K --warmup W [--workload render|train|dnerf] [--size 800]
 
 A step = one full render of a synthetic 800x800 view (BASELINE.json configs[1]: D=8/W=256 coarse+fine
 nets, multires 10/4, view directions, white background, near/far 2/6, chunk 32768, perturb=0) through
@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="render", choices=["render", "train"])
+    ap.add_argument("--workload", default="render", choices=["render", "train", "dnerf"])
     ap.add_argument("--size", type=int, default=800, help="image side (render workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")
@@ -130,6 +130,9 @@ def main():
     if args.workload == "train":
         from bench_train import run_train
         return run_train(args, torch, dist, world, rank, device)
+    if args.workload == "dnerf":
+        from bench_dnerf import run_dnerf
+        return run_dnerf(args, torch, dist, world, rank, device)
 
     coarse, fine = build_nets(torch, device)
     e10, _ = get_embedder(10, 0)

@@ -1,0 +1,106 @@
+"""bench.py --workload dnerf: BASELINE.json configs[4] -- D-NeRF deformation chain (vanilla_dynamic): one
+800x800 view at time t through render_dnerf(), 64 coarse + 128 fine samples, ONE DNeRF_Deformation model for
+both passes (create_dnerf's default, use_two_models_for_fine=False), time net D=8/W=256 on gamma(x) (+) gamma(t),
+canonical net D=8/W=256 with view directions.  With N ranks the image rows are sharded as in the render bench."""
+import json
+import time
+
+import numpy as np
+
+TIME_MAC = (63 + 21) * 256 + 6 * 256 * 256 + (256 + 63) * 256 + 256 * 3          # 497 152
+OCC_MAC = 63 * 256 + 6 * 256 * 256 + 319 * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3   # 593 408
+FLOP_PER_POINT = 2 * (TIME_MAC + OCC_MAC)
+
+
+def run_dnerf(args, torch, dist, world, rank, device):
+    import nerf_fixtures as fx
+    import nerf_amd.vanilla_dynamic as vd
+    from bench import PEAK_F32_MFMA_TFLOPS
+    from nerf_amd import parallel
+    from nerf_amd.rays import get_rays
+
+    embed_fn, _ = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = vd.get_time_embedder(10)
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                 input_ch_time=21, output_ch=5, skips=[4], use_viewdirs=True, zero_canonical=True)
+    sd = fx.make_dnerf_state(31, peaky=True, dx_scale=3.0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(device)
+    model.embed_fn = embed_fn
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+    H = W = args.size
+    K, _ = fx.intrinsics(H, W)
+
+    events, enabled = [], [False]
+    orig = vd.DNeRF_Deformation.query_points
+
+    def timed(self, pts, *a, **k):
+        if not enabled[0]:
+            return orig(self, pts, *a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(self, pts, *a, **k)
+        e1.record()
+        events.append((e0, e1, pts.shape[0]))
+        return out
+    vd.DNeRF_Deformation.query_points = timed
+
+    def step(i):
+        c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
+        tval = 0.1 + 0.8 * ((i * 7) % 10) / 10.0
+        with torch.no_grad():
+            if world == 1:
+                return vd.render_dnerf(H, W, K, tval, chunk=32768, c2w=c2w, near=2., far=6., **kw)[0]
+            ro_full, rd_full = get_rays(H, W, K, c2w)
+
+            def rows(row0, nrows):
+                rays = torch.stack([ro_full[row0:row0 + nrows].reshape(-1, 3), rd_full[row0:row0 + nrows].reshape(-1, 3)])
+                rgb, disp, acc, _ = vd.render_dnerf(H, W, K, tval, chunk=32768, rays=rays, near=2., far=6., **kw)
+                return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+            return parallel.render_sharded(rows, H, W, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    enabled[0] = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    enabled[0] = False
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        q_ms = sum(a.elapsed_time(b) for a, b, _ in events)
+        q_pts = sum(n for _, _, n in events)
+        achieved = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12 if q_ms > 0 else 0.0
+        out = {
+            "metric": "rays/sec at 64+128 samples/ray (D-NeRF deformation render)",
+            "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"D-NeRF bouncingballs-shaped {H}x{W} view, deformation network (time net D=8 W=256 -> "
+                                   "dx -> canonical net D=8 W=256), 64+128 samples, one model for both passes, fp32",
+                       "rays_per_step": H * W,
+                       "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "dnerf_query_fwd_kernel<8> (gamma(x), gamma(t), time net, re-embed, canonical net)",
+                         "launches": len(events), "avg_launch_ms": q_ms / max(len(events), 1),
+                         "flop_per_point": FLOP_PER_POINT, "query_share_of_step": q_ms * 1e-3 / dt},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -100,18 +100,19 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_kernel(const DnerfArgs
         // network.py:331-333: deformed point, re-embedded; with dx == 0 this is the original embedding
         px = px + dx0; py = py + dx1; pz = pz + dx2;
         fill_pe3<kKsX>(xin, px, py, pz, a.cplan.x_param, h);
-        float din[kKsD];
-        const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
-        fill_pe3<kKsD>(din, d[0], d[1], d[2], a.cplan.d_param, h);
         trunk_fwd<NT>(a.cplan, wc, xin, tin, false, hin, acc);
         if constexpr (NT >= 2) {
             const NetPlan &pl = a.cplan;
             const float alpha = head_dot<NT>(hin, wc, (uint32_t)pl.alpha_vec) + wload1(wc, (uint32_t)pl.alpha_b * 4);
             load_bias<NT>(acc, wc, (uint32_t)pl.feat_b);
             gemm_hid<NT, NT>(acc, hin, wc, (uint32_t)pl.feat_w);
+            relu_move<NT>(hin, acc, false);   // feature vector -> operand registers (no ReLU)
             f32x16 acc2[NT / 2];
             load_bias<NT / 2>(acc2, wc, (uint32_t)pl.views_b);
-            gemm_hid<NT, NT / 2>(acc2, acc, wc, (uint32_t)pl.views_w_hid);
+            gemm_hid<NT, NT / 2>(acc2, hin, wc, (uint32_t)pl.views_w_hid);
+            float din[kKsD];                  // built here: the trunk has no registers to spare for it
+            const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
+            fill_pe3<kKsD>(din, d[0], d[1], d[2], a.cplan.d_param, h);
             gemm_in<kKsD, NT / 2>(acc2, din, wc, (uint32_t)pl.views_w_in);
             relu_move<NT / 2>(acc2, acc2, true);
             const uint32_t rv = (uint32_t)pl.rgb_vec, rb = (uint32_t)pl.rgb_b * 4;

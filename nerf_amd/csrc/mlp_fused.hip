@@ -47,25 +47,17 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
         const int64_t p = tile * 32 + n;
         const int64_t pc = p < a.n_points ? p : a.n_points - 1;
         float xin[kKsX];
-        float din[kKsD];
         if constexpr (EMB) {
-            const float *row = a.pts + pc * a.x_stride;
-            fill_raw<kKsX>(xin, row, pl.x_param, h);
-            if (pl.use_viewdirs) fill_raw<kKsD>(din, row + a.input_ch, pl.d_param, h);
+            fill_raw<kKsX>(xin, a.pts + pc * a.x_stride, pl.x_param, h);
         } else {
             const float *q = a.pts + pc * 3;
             fill_pe3<kKsX>(xin, q[0], q[1], q[2], pl.x_param, h);
-            if (pl.use_viewdirs) {
-                const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
-                fill_pe3<kKsD>(din, d[0], d[1], d[2], pl.d_param, h);
-            }
         }
 
         TBuf tb;
         if constexpr (TRAIN) {
             tb = make_tbuf(a.acts + tile * a.tl.a_tile, a.tl.a_tile, lane);
             store_in_t8<kKsX>(tb, (uint32_t)a.tl.a_xin, xin);
-            if (pl.use_viewdirs) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
         }
         f32x16 hin[NT], acc[NT];
         // trunk (network.py:48-53)
@@ -92,6 +84,15 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 f32x16 acc2[NT / 2];
                 load_bias<NT / 2>(acc2, wb, (uint32_t)pl.views_b);                               // network.py:58-62
                 gemm_hid<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid);
+                // the direction encoding is built here, not at the top: 16 registers the trunk cannot spare
+                float din[kKsD];
+                if constexpr (EMB) {
+                    fill_raw<kKsD>(din, a.pts + pc * a.x_stride + a.input_ch, pl.d_param, h);
+                } else {
+                    const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
+                    fill_pe3<kKsD>(din, d[0], d[1], d[2], pl.d_param, h);
+                }
+                if constexpr (TRAIN) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
                 gemm_in<kKsD, NT / 2>(acc2, din, wb, (uint32_t)pl.views_w_in);
                 relu_move<NT / 2>(acc2, acc2, true);
                 if constexpr (TRAIN) store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);
