@@ -85,6 +85,55 @@ class QueryTimer:
         return ms, pts, len(self.events)
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json, latest round;
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command, FETCH doubled as the
+    gfx950 note in MI355X_MICROARCH.md prescribes).  None when no PMC file is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))[workload][kernel]["hbm_bytes"]
+    except (KeyError, ValueError):
+        return None
+
+
+def hbm_kernels(torch, device, n_rays=32768, reps=20):
+    """Achieved GB/s of the sampling / compositing kernels at the render chunk size: algorithmic bytes per launch
+    (inputs read once + outputs written once) over the HIP-event duration, `reps` back-to-back launches."""
+    import nerf_fixtures as fx
+    from nerf_amd import ops
+    rays = torch.from_numpy(fx.blender_rays(n_rays, 3)).to(device)
+    z64 = ops.sample_coarse(rays, 64)
+    w64 = torch.rand(n_rays, 64, device=device)
+    _, z192, _ = ops.sample_fine(z64, w64, 128, None, want_samples=False)
+    raw192 = torch.randn(n_rays, 192, 4, device=device)
+    ncol = rays.shape[1]
+    cases = {
+        "sample_coarse_kernel (S=64)": (lambda: ops.sample_coarse(rays, 64), 4 * (ncol + 64)),
+        "points_kernel (S=192)": (lambda: ops.points(rays, z192), 4 * (ncol + 192 + 3 * 192)),
+        "sample_fine_kernel (64 -> 64+128)": (lambda: ops.sample_fine(z64, w64, 128, None, want_samples=False),
+                                              4 * (64 + 64 + 192 + 1)),
+        "composite_fwd_kernel (S=192)": (lambda: ops.composite_fwd(raw192, z192, rays[:, 3:6], None, True),
+                                         4 * (4 * 192 + 192 + 3 + 3 + 1 + 1 + 192 + 1)),
+    }
+    out = {}
+    for name, (fn, bytes_per_ray) in cases.items():
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        gbs = bytes_per_ray * n_rays / (us * 1e-6) / 1e9
+        out[name] = {"us_per_launch": round(us, 2), "bytes_per_ray": bytes_per_ray, "GB/s": round(gbs, 1),
+                     "frac_of_8TB/s": round(gbs / 8000.0, 4)}
+    return out
+
+
 def cpu_baseline(n_rays):
     """The oracle (C restatement of the reference's CPU path) on a bounded sample of the same workload."""
     import nerf_fixtures as fx
@@ -200,12 +249,13 @@ def main():
                                    "fp32, chunk 32768", "rays_per_step": n_rays,
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("render", "query_fwd_kernel"),
                          "kernel": "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)",
                          "launches": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": q_pts / max(q_n, 1),
                          "query_share_of_step": q_ms * 1e-3 / dt},
         }
+        out["hbm_kernels"] = hbm_kernels(torch, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays)
         print(json.dumps(out), flush=True)

@@ -12,6 +12,21 @@ FWD_FLOP_PER_POINT = 1186816
 STEP_FLOP_PER_POINT = 2 * 1744512   # fwd + dgrad + wgrad, SURVEY 8d
 
 
+def step_traffic():
+    """HBM bytes per training step summed over this library's kernels, from the committed PMC passes."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1]))["train"]
+        return sum(v["launches"] * v["hbm_bytes"] for k, v in t.items() if isinstance(v, dict) and "hbm_bytes" in v) \
+            / t["_steps_profiled"]
+    except (KeyError, ValueError):
+        return None
+
+
 def run_train(args, torch, dist, world, rank, device):
     import nerf_fixtures as fx
     from bench import PEAK_F32_MFMA_TFLOPS, build_nets
@@ -77,9 +92,9 @@ def run_train(args, torch, dist, world, rank, device):
                                    "fp32, forward+backward+Adam", "global_batch_rays": n_global,
                        "parallelism": f"dp{world}, one flat all-reduce (4.77 MB)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": step_traffic(),
                          "kernel": "whole step (query_fwd<train> + dgrad + wgrad kernels); algorithmic "
-                                   "3.489 MFLOP/point over wall time"},
+                                   "3.489 MFLOP/point over wall time; traffic = HBM bytes per STEP over all kernels"},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

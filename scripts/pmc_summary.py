@@ -10,6 +10,9 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
     name = name.split("(")[0]
     return name[-90:]
 
