@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_POINT = 2 * (63 * 256 + 6 * 256 * 256 + 319 * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3)  # 1 186 816
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def parse():
@@ -37,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="render", choices=["render", "train", "dnerf"])
     ap.add_argument("--size", type=int, default=800, help="image side (render workload)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -65,19 +68,24 @@ class QueryTimer:
 
     def install(self):
         from nerf_amd import ops
-        orig, timer, torch = ops.PackedNet.query, self, self.torch
+        timer, torch = self, self.torch
 
-        def timed(pk, pts, viewdirs=None, pts_per_ray=1):
-            if not timer.enabled:
-                return orig(pk, pts, viewdirs, pts_per_ray)
-            pk.refresh()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(pk, pts, viewdirs, pts_per_ray)
-            e1.record()
-            timer.events.append((e0, e1, pts.shape[0]))
-            return out
-        ops.PackedNet.query = timed
+        def wrap(cls):
+            orig = cls.query
+
+            def timed(pk, pts, viewdirs=None, pts_per_ray=1):
+                if not timer.enabled:
+                    return orig(pk, pts, viewdirs, pts_per_ray)
+                pk.refresh()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(pk, pts, viewdirs, pts_per_ray)
+                e1.record()
+                timer.events.append((e0, e1, pts.shape[0]))
+                return out
+            cls.query = timed
+        wrap(ops.PackedNet)
+        wrap(ops.PackedNetBf16)
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
@@ -184,6 +192,9 @@ def main():
         return run_dnerf(args, torch, dist, world, rank, device)
 
     coarse, fine = build_nets(torch, device)
+    coarse.precision = fine.precision = args.precision
+    bf16 = args.precision == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     e10, _ = get_embedder(10, 0)
     e4, _ = get_embedder(4, 0)
     kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
@@ -243,14 +254,17 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"lego-shaped {H}x{W} test-view render, 64+128 samples, D=8 W=256 coarse+fine, "
-                                   "fp32, chunk 32768", "rays_per_step": n_rays,
+                                   f"{args.precision}, chunk 32768", "rays_per_step": n_rays,
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("render", "query_fwd_kernel"),
-                         "kernel": "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
+                         "traffic": pmc_traffic("render_bf16" if bf16 else "render",
+                                                "query_fwd_bf16_kernel" if bf16 else "query_fwd_kernel"),
+                         "kernel": "query_fwd_bf16_kernel<8> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)" if bf16
+                         else "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)",
                          "launches": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": q_pts / max(q_n, 1),
                          "query_share_of_step": q_ms * 1e-3 / dt},

@@ -125,6 +125,15 @@ int nrf_dnerf_query_fwd(const nrf_net_t *time_net, const nrf_net_t *occ_net, con
                         const float *times, int64_t n_points, int32_t pts_per_ray, int32_t times_per_point,
                         int64_t netchunk, int32_t zero_canonical, float *raw, float *dx, void *stream);
 
+/* ---- bf16 MFMA variant of the network query (BASELINE north star: "optional bf16 variant"; no counterpart in the
+ * reference, which is fp32 only).  Same arguments and results as nrf_query_fwd with embed mode 0, computed with
+ * bf16 weights / activations and f32 accumulation (v_mfma_f32_32x32x16_bf16); tolerance 1e-2 on rendered values.
+ * `packed` is a separate bf16 weight stream of nrf_mlp_bf16_packed_bytes() bytes.  Inference only. */
+int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
+int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                       const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
+
 /* K4  raw2outputs -- render.py:82-131.  raw [N,S,4], z_vals [N,S], rays_d rows of `d_stride` floats
  * (pass rays+3 with d_stride = ncol to read directions out of the ray matrix), noise NULL or [N,S]
  * (already multiplied by raw_noise_std).  Outputs rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]. */

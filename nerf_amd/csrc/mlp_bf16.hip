@@ -1,0 +1,444 @@
+// bf16 variant of the fused positional-encoding + NeRF MLP query: v_mfma_f32_32x32x16_bf16, gfx950.
+//
+// Same transposed-product chaining as the f32 kernel (mlp_fused.hip): out^T[channel, point] = W * act^T, the
+// accumulators of one layer ARE the B operand of the next after a pairwise f32->bf16 pack (no LDS, no lane
+// movement for activations).  What changes with a 16x faster matrix pipe is the weight traffic: per-wave
+// streaming from L2 would need ~128 B/clk/CU, more than L2 delivers.  So here
+//   * a wave owns 64 points (two 32-point MFMA column tiles): every weight fragment feeds two MFMAs;
+//   * the 4 waves of a workgroup share the weights through LDS: the net's weights are ONE linear stream of
+//     16 KiB chunks (16 A-fragments of 1 KiB, in the exact order the MFMAs consume them); each wave copies a
+//     quarter of the next chunk global->LDS with buffer_load ... lds (no registers) while the current chunk is
+//     being consumed; one barrier per chunk (1024 MFMA cycles);
+//   * the bias rides in the GEMM as a constant-1 input channel (the encoders' pad slot, or one extra k-step);
+//   * alpha / rgb heads are one-output-tile GEMMs on the same stream;
+//   * gamma(x): one accurate sincosf per coordinate at the lane's base frequency, higher octaves by the
+//     double-angle recurrence (error ~2^-16, far below bf16's 2^-9 rounding of the encoded value).
+// Inference only; training stays on the exact f32 kernels.
+#include "mlp_device.h"
+
+namespace nrf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kChunk = 16384;   // bytes per LDS stage: 16 A-fragments (one 32x16 bf16 tile = 1 KiB per wave load)
+constexpr int kFrag = 1024;
+
+// ---- channel maps (shared by the pack kernel and the query kernel) -----------------------------------
+// A k-step is one MFMA (16 input channels): lane half h supplies elements j = 0..7 (k = 8h + j).
+// Encoded inputs: lane half h owns a LOCAL list of 8*KS slots; k-step s takes slots 8s..8s+7.
+//   gamma(3-vector), L frequencies: slot 0: x | z, slot 1: y | CONST 1 (bias), then per frequency f = 2i + h:
+//   sin(2^f x y z), cos(2^f x y z).   Returns the reference channel (positional_encoding.py:11-36), -1 = zero
+//   pad, -2 = the constant-1 channel.
+NRF_HD inline int bf_pe3_chan(int L, int h, int slot) {
+    if (slot == 0) return h ? 2 : 0;
+    if (slot == 1) return h ? -2 : 1;
+    int q = slot - 2, i = q / 6, r = q - 6 * i, f = 2 * i + h;
+    return f < L ? 3 + 6 * f + r : -1;
+}
+//   gamma(scalar) (D-NeRF time): slot 0: t | pad, then per frequency f = 2i + h: sin, cos.
+NRF_HD inline int bf_pe1_chan(int L, int h, int slot) {
+    if (slot == 0) return h ? -1 : 0;
+    int q = slot - 1, i = q >> 1, r = q & 1, f = 2 * i + h;
+    return f < L ? 1 + 2 * f + r : -1;
+}
+//   previous layer's accumulators: k-step s = (tile s>>1, register half s&1); element j = register 8(s&1) + j
+NRF_HD inline int bf_hid_chan(int h, int s, int j) {
+    int t = s >> 1, r = 8 * (s & 1) + j;
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+enum { BFB_NONE = 0, BFB_HIDDEN = 1, BFB_PE3 = 2, BFB_PE1 = 3, BFB_BIAS = 4 };
+struct BfBlock { int32_t type, param, ksteps, col0, ncols; };
+struct BfLayer {
+    const float *W, *b;
+    int32_t ld, n_out, nt_out, nblk;
+    BfBlock blk[3];
+    int64_t dst;   // byte offset in the stream
+};
+
+// one thread = one lane's 16 bytes (8 bf16) of one A fragment
+__global__ void pack_bf16_kernel(BfLayer a, char *stream) {
+    int ks_total = 0;
+    for (int i = 0; i < a.nblk; ++i) ks_total += a.blk[i].ksteps;
+    const int64_t nthreads = (int64_t)ks_total * a.nt_out * 64;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < nthreads; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = idx & 63, frag = (int)(idx >> 6);
+        const int t = frag % a.nt_out;
+        int s = frag / a.nt_out;
+        int bi = 0;
+        while (s >= a.blk[bi].ksteps) { s -= a.blk[bi].ksteps; ++bi; }
+        const BfBlock B = a.blk[bi];
+        const int m = lane & 31, h = lane >> 5, out = 32 * t + m;
+        bf16x8 v;
+        for (int j = 0; j < 8; ++j) {
+            int ch = -1;
+            switch (B.type) {
+                case BFB_HIDDEN: ch = bf_hid_chan(h, s, j); break;
+                case BFB_PE3: ch = bf_pe3_chan(B.param, h, 8 * s + j); break;
+                case BFB_PE1: ch = bf_pe1_chan(B.param, h, 8 * s + j); break;
+                case BFB_BIAS: ch = (h == 0 && j == 0) ? -2 : -1; break;
+            }
+            float w = 0.0f;
+            if (out < a.n_out) {
+                if (ch >= 0 && ch < B.ncols) w = a.W[(int64_t)out * a.ld + B.col0 + ch];
+                else if (ch == -2) w = a.b[out];
+            }
+            v[j] = (__bf16)w;
+        }
+        *reinterpret_cast<bf16x8 *>(stream + a.dst + (int64_t)frag * kFrag + lane * 16) = v;
+    }
+}
+
+// ---- host-side stream plan --------------------------------------------------------------------------
+struct BfPlan {
+    BfLayer layer[2 * NRF_MAX_D + 8];
+    int n = 0;
+    int64_t bytes = 0;
+    const char *err = nullptr;
+    void add(const float *W, const float *b, int ld, int n_out, int nt_out, BfBlock b0, BfBlock b1 = {}, BfBlock b2 = {}) {
+        BfLayer &L = layer[n++];
+        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out;
+        L.blk[0] = b0; L.blk[1] = b1; L.blk[2] = b2;
+        L.nblk = 1 + (b1.type != BFB_NONE) + (b2.type != BFB_NONE);
+        L.dst = bytes;
+        int ks = b0.ksteps + b1.ksteps + b2.ksteps;
+        bytes += (int64_t)ks * nt_out * kFrag;
+    }
+};
+
+constexpr int kBfKsX = 4, kBfKsD = 2, kBfKsT = 2;   // k-steps of the encoded inputs (64 / 32 / 32 slots over both halves)
+
+static const char *bf_check_net(const nrf_net_t *net, const nrf_embed_t *emb, bool time_net) {
+    if (emb->mode != 0) return "the bf16 kernels take raw points (embed mode 0) only";
+    if (net->W != 64 && net->W != 128 && net->W != 256) return "W must be 64, 128 or 256";
+    if (net->D < 1 || net->D > NRF_MAX_D) return "D out of range";
+    if (emb->multires < 0 || emb->multires > 10 || net->input_ch != 3 + 6 * emb->multires)
+        return "input_ch must equal 3 + 6*multires with multires <= 10";
+    if (time_net) {
+        if (emb->multires_time < 0 || emb->multires_time > 10 || net->input_ch_views != 1 + 2 * emb->multires_time)
+            return "time channels must equal 1 + 2*multires_time with multires_time <= 10";
+    } else if (net->use_viewdirs) {
+        if (emb->multires_views < 0 || emb->multires_views > 4 || net->input_ch_views != 3 + 6 * emb->multires_views)
+            return "input_ch_views must equal 3 + 6*multires_views with multires_views <= 4";
+    } else if (net->output_ch < 1 || net->output_ch > 8) {
+        return "output_ch must be 1..8 without view directions";
+    }
+    return nullptr;
+}
+
+// Appends one net's layers in the order the kernel consumes them.  time_net: layer 0 reads cat[gamma(x), gamma(t)],
+// the output layer is `out_w` (W -> 3).
+static void bf_plan_net(BfPlan &P, const nrf_net_t *net, const nrf_embed_t *emb, bool time_net) {
+    const int W = net->W, nt = W / 32, ic = net->input_ch, D = net->D;
+    const BfBlock X{BFB_PE3, emb->multires, kBfKsX, 0, ic};
+    const BfBlock none{};
+    if (time_net)
+        P.add(net->pts_w[0], net->pts_b[0], ic + net->input_ch_views, W, nt, X,
+              BfBlock{BFB_PE1, emb->multires_time, kBfKsT, ic, net->input_ch_views});
+    else
+        P.add(net->pts_w[0], net->pts_b[0], ic, W, nt, X);
+    for (int i = 1; i < D; ++i) {
+        const bool skip = (net->skips_mask >> (i - 1)) & 1;   // network.py:52-53
+        if (skip)
+            P.add(net->pts_w[i], net->pts_b[i], W + ic, W, nt, X, BfBlock{BFB_HIDDEN, 0, 2 * nt, ic, W});
+        else
+            P.add(net->pts_w[i], net->pts_b[i], W, W, nt, BfBlock{BFB_HIDDEN, 0, 2 * nt, 0, W}, BfBlock{BFB_BIAS, 0, 1, 0, 0});
+    }
+    const BfBlock H{BFB_HIDDEN, 0, 2 * nt, 0, W}, Bi{BFB_BIAS, 0, 1, 0, 0};
+    if (time_net || !net->use_viewdirs) {
+        P.add(net->out_w, net->out_b, W, time_net ? 3 : net->output_ch, 1, H, Bi);
+        return;
+    }
+    P.add(net->alpha_w, net->alpha_b, W, 1, 1, H, Bi);                         // network.py:56
+    P.add(net->feature_w, net->feature_b, W, W, nt, H, Bi);                    // network.py:57
+    P.add(net->views_w, net->views_b, W + net->input_ch_views, W / 2, nt / 2, H,
+          BfBlock{BFB_PE3, emb->multires_views, kBfKsD, W, net->input_ch_views});   // network.py:58-62 (bias: CONST slot)
+    P.add(net->rgb_w, net->rgb_b, W / 2, 3, 1, BfBlock{BFB_HIDDEN, 0, nt, 0, W / 2}, Bi);   // network.py:64
+}
+
+static int bf_pack(const BfPlan &P, void *packed, hipStream_t st) {
+    for (int i = 0; i < P.n; ++i) {
+        const BfLayer &L = P.layer[i];
+        if (!L.W || !L.b) return nrf::fail(NRF_ERR_INVALID, "bf16 pack: a parameter pointer of the net is null (layer %d)", i);
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(128), dim3(256), 0, st, L, (char *)packed);
+    }
+    // tail pad: the loader always copies a full 16 KiB stage
+    if (hipMemsetAsync((char *)packed + P.bytes, 0, kChunk, st) != hipSuccess)
+        return nrf::fail(NRF_ERR_LAUNCH, "bf16 pack: hipMemsetAsync failed");
+    return check_launch("nrf_mlp_bf16_pack_weights");
+}
+
+// ---- device side ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+// ReLU on a packed bf16 pair: as signed 16-bit integers negative floats are negative, so max(.., 0) clears them
+__device__ __forceinline__ uint32_t relu2(uint32_t p) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
+}
+
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    char *lds;           // the workgroup's two stages
+    uint32_t pf_off;     // byte offset (in the stream) of the chunk most recently requested
+    uint32_t cur;        // stage holding the chunk about to be consumed (0 | 1), wave-uniform
+    uint32_t rd;         // this lane's byte offset in `lds` for fragment 0 of the current chunk
+    int lane16, wave;
+
+    __device__ __forceinline__ void request(uint32_t off, uint32_t stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t f = (uint32_t)wave + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + stage * kChunk + f * kFrag),
+                                                     16, lane16, (int)(off + f * kFrag), 0, 0);
+        }
+    }
+    // Make the next chunk (of `bytes` bytes) current: own copies landed, then the barrier (everyone's copies
+    // landed, everyone is done reading the other stage), then request the chunk after it into that other stage.
+    __device__ __forceinline__ void acquire(uint32_t bytes, bool last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        pf_off = last ? 0u : pf_off + bytes;
+        request(pf_off, cur ^ 1u);
+        rd = (uint32_t)lane16 + cur * kChunk;
+        cur ^= 1u;
+    }
+    __device__ __forceinline__ bf16x8 frag(int f) const {
+        return *reinterpret_cast<const bf16x8 *>(lds + rd + f * kFrag);
+    }
+};
+
+// acc[p][t] (+)= W_layer * B(p, s) over the layer's S k-steps; B(p, s) = 8 bf16 of point tile p for k-step s.
+template <int NT_OUT, int S, bool LAST, class BF>
+__device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st, BF &&B) {
+    constexpr int KC = 16 / NT_OUT;
+    constexpr int NCH = (S + KC - 1) / KC;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ks = (S - c * KC) < KC ? (S - c * KC) : KC;
+        st.acquire((uint32_t)(ks * NT_OUT * kFrag), LAST && c == NCH - 1);
+#pragma unroll
+        for (int s = 0; s < ks; ++s) {
+            const int sg = c * KC + s;
+            const bf16x8 b0 = B(0, sg), b1 = B(1, sg);
+#pragma unroll
+            for (int t = 0; t < NT_OUT; ++t) {
+                const bf16x8 a = st.frag(s * NT_OUT + t);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, sg == 0 ? zero : acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, sg == 0 ? zero : acc[1][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// accumulators -> next layer's B fragments: k-step 2t+e = registers 8e..8e+7 of tile t, packed pairwise
+template <int NT>
+__device__ __forceinline__ void pack_acts(u32x4v (&hin)[2][2 * NT], const f32x16 (&acc)[2][NT], bool relu) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t v = pack2(acc[p][t][8 * e + 2 * w], acc[p][t][8 * e + 2 * w + 1]);
+                    hin[p][2 * t + e][w] = relu ? relu2(v) : v;
+                }
+}
+
+// gamma(v) of a 3-vector into KS k-step fragments (slot order of bf_pe3_chan)
+template <int KS>
+__device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float y, float z, int L, int h) {
+    constexpr int NF = (8 * KS - 2) / 6;
+    float v[8 * KS];
+    v[0] = h ? z : x;
+    v[1] = h ? 1.0f : y;
+    const float sc = pow2i(h);
+    float s[3], c[3];
+    sincosf(x * sc, &s[0], &c[0]);
+    sincosf(y * sc, &s[1], &c[1]);
+    sincosf(z * sc, &s[2], &c[2]);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            v[2 + 6 * i + d] = s[d];
+            v[2 + 6 * i + 3 + d] = c[d];
+            if (i + 1 < NF) {   // two octaves up: angle * 4
+                const float s2 = 2.0f * s[d] * c[d], c2 = 1.0f - 2.0f * s[d] * s[d];
+                s[d] = 2.0f * s2 * c2;
+                c[d] = 1.0f - 2.0f * s2 * s2;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 2 + 6 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
+    (void)L;   // frequencies >= L meet zero weights
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) out[k][w] = pack2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
+}
+
+struct Bf16Args {
+    const char *stream;
+    int64_t stream_bytes;    // without the tail pad
+    const float *pts, *viewdirs;
+    float *raw;
+    int64_t n_points;
+    int32_t pts_per_ray, n_trunk, skip_in_mask, use_viewdirs, output_ch, Lx, Ld, pad_;
+};
+
+__device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * kChunk];
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    WStream st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)(a.stream_bytes + kChunk), 0x00020000);
+    st.lds = lds;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.pf_off = 0;
+    st.cur = 0;
+    st.rd = 0;
+    st.request(0, 0);
+
+    const int64_t ntiles = (a.n_points + 255) >> 8;
+    u32x4v one;   // the constant-1 channel of a bias k-step: element 0 of lane half 0
+    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t pp[2], pc[2];
+        u32x4v xin[2][kBfKsX];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pp[p] = tile * 256 + st.wave * 64 + p * 32 + n;
+            pc[p] = pp[p] < a.n_points ? pp[p] : a.n_points - 1;
+            const float *q = a.pts + pc[p] * 3;
+            fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], a.Lx, h);
+        }
+        f32x16 acc[2][NT];
+        u32x4v hin[2][2 * NT];
+        gemm_layer<NT, kBfKsX, false>(acc, st, [&](int p, int s) { return as_bf(xin[p][s]); });     // network.py:48-51
+        pack_acts<NT>(hin, acc, true);
+        for (int l = 1; l < a.n_trunk; ++l) {
+            if ((a.skip_in_mask >> l) & 1)                                                        // network.py:52-53
+                gemm_layer<NT, kBfKsX + 2 * NT, false>(acc, st, [&](int p, int s) {
+                    return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
+                });
+            else
+                gemm_layer<NT, 2 * NT + 1, false>(acc, st, [&](int p, int s) {
+                    return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
+                });
+            pack_acts<NT>(hin, acc, true);
+        }
+        auto Hb = [&](int p, int s) { return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one); };
+        if (a.use_viewdirs) {
+            if constexpr (NT >= 2) {
+                f32x16 acc1[2][1];
+                gemm_layer<1, 2 * NT + 1, false>(acc1, st, Hb);                                    // network.py:56
+                const float alpha0 = acc1[0][0][0], alpha1 = acc1[1][0][0];
+                gemm_layer<NT, 2 * NT + 1, false>(acc, st, Hb);                                    // network.py:57
+                pack_acts<NT>(hin, acc, false);
+                u32x4v din[2][kBfKsD];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
+                    fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], a.Ld, h);
+                }
+                f32x16 acc2[2][NT / 2];
+                gemm_layer<NT / 2, 2 * NT + kBfKsD, false>(acc2, st, [&](int p, int s) {          // network.py:58-62
+                    return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
+                });
+                u32x4v hv[2][NT];
+                pack_acts<NT / 2>(hv, acc2, true);
+                gemm_layer<1, NT + 1, true>(acc1, st, [&](int p, int s) {                          // network.py:64
+                    return s < NT ? as_bf(hv[p][s < NT ? s : 0]) : as_bf(one);
+                });
+                if (h == 0) {
+                    if (pp[0] < a.n_points)
+                        reinterpret_cast<float4 *>(a.raw)[pp[0]] = make_float4(acc1[0][0][0], acc1[0][0][1], acc1[0][0][2], alpha0);
+                    if (pp[1] < a.n_points)
+                        reinterpret_cast<float4 *>(a.raw)[pp[1]] = make_float4(acc1[1][0][0], acc1[1][0][1], acc1[1][0][2], alpha1);
+                }
+            }
+        } else {
+            f32x16 acc1[2][1];
+            gemm_layer<1, 2 * NT + 1, true>(acc1, st, Hb);                                         // network.py:67
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 4 * h + r;   // rows 0-3 on lane half 0, 4-7 on half 1 (registers 0..3)
+                    if (o < a.output_ch && pp[p] < a.n_points) a.raw[pp[p] * a.output_ch + o] = acc1[p][0][r];
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last request must land before the LDS is released
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+    if (!net || !emb) return -1;
+    if (const char *e = bf_check_net(net, emb, false)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16_packed_bytes: %s", e); return -1; }
+    BfPlan P;
+    bf_plan_net(P, net, emb, false);
+    return P.bytes + kChunk;
+}
+
+extern "C" int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    NRF_REQUIRE(net && emb && packed, "nrf_mlp_bf16_pack_weights: null pointer");
+    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16_pack_weights: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nrf_mlp_bf16_pack_weights: packed must be 16-byte aligned");
+    BfPlan P;
+    bf_plan_net(P, net, emb, false);
+    return bf_pack(P, packed, as_stream(stream));
+}
+
+extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                  const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
+    NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd_bf16: null pointer");
+    NRF_REQUIRE(n_points >= 0, "nrf_query_fwd_bf16: negative n_points");
+    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd_bf16: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
+                "nrf_query_fwd_bf16: packed and raw must be 16-byte aligned");
+    if (net->use_viewdirs) {
+        NRF_REQUIRE(viewdirs, "nrf_query_fwd_bf16: viewdirs is null but the net uses view directions");
+        NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0,
+                    "nrf_query_fwd_bf16: n_points (%lld) must be a multiple of pts_per_ray (%d)", (long long)n_points, pts_per_ray);
+    }
+    if (n_points == 0) return NRF_OK;
+    BfPlan P;
+    bf_plan_net(P, net, emb, false);
+    Bf16Args a{};
+    a.stream = (const char *)packed; a.stream_bytes = P.bytes;
+    a.pts = pts; a.viewdirs = viewdirs; a.raw = raw; a.n_points = n_points;
+    a.pts_per_ray = pts_per_ray > 0 ? pts_per_ray : 1;
+    a.n_trunk = net->D;
+    a.skip_in_mask = 0;
+    for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
+    a.use_viewdirs = net->use_viewdirs; a.output_ch = net->output_ch;
+    a.Lx = emb->multires; a.Ld = emb->multires_views;
+    const int64_t ntiles = (n_points + 255) / 256;
+    const int blocks = (int)(ntiles < 256 ? ntiles : 256);   // 512 registers per lane: one workgroup per CU
+    hipStream_t st = as_stream(stream);
+    switch (net->W / 32) {
+        case 8: hipLaunchKernelGGL((query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((query_fwd_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((query_fwd_bf16_kernel<2>), dim3(blocks), dim3(256), 0, st, a); break;
+    }
+    return check_launch("nrf_query_fwd_bf16");
+}

@@ -62,20 +62,31 @@ class NeRF(nn.Module):
         else:
             self.output_linear = nn.Linear(W, output_ch)
         self._packed_cache = {}
+        # "fp32" (exact f32 MFMA, the reference's arithmetic) or "bf16" (bf16 MFMA, f32 accumulate; inference
+        # through render()'s fused query only).  Not part of the reference's constructor: set as an attribute.
+        self.precision = "fp32"
 
     # ------------------------------------------------------------------ packed weights
     def _packed(self, key):
         """key = (mode, multires, multires_views)."""
         pk = self._packed_cache.get(key)
         if pk is None:
-            params = dict(self.named_parameters())
-            if not self.use_viewdirs:
-                params = {k: v for k, v in params.items() if not k.startswith("views_linears")}
-            mode, L, Lv = key
-            pk = ops.PackedNet(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
-                               list(self.skips), self.use_viewdirs, mode=mode, multires=L, multires_views=Lv)
+            params = self._pack_params()
+            mode, L, Lv = key[:3]
+            if len(key) > 3 and key[3] == "bf16":
+                pk = ops.PackedNetBf16(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
+                                       list(self.skips), self.use_viewdirs, multires=L, multires_views=Lv)
+            else:
+                pk = ops.PackedNet(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
+                                   list(self.skips), self.use_viewdirs, mode=mode, multires=L, multires_views=Lv)
             self._packed_cache[key] = pk
         return pk
+
+    def _pack_params(self):
+        params = dict(self.named_parameters())
+        if not self.use_viewdirs:
+            params = {k: v for k, v in params.items() if not k.startswith("views_linears")}
+        return params
 
     def _apply(self, fn, *args, **kwargs):  # .to()/.cuda() replace parameter tensors: drop stale packed copies
         self._packed_cache = {}
@@ -103,8 +114,11 @@ class NeRF(nn.Module):
     def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
         """pts [P,3]; viewdirs [P/pts_per_ray, 3] or None -> raw [P, 4|output_ch] (render.py:31-56 fused)."""
         key = (0, multires, multires_views if self.use_viewdirs else 0)
+        need_grad = self._need_grad(pts)
+        if self.precision == "bf16" and not need_grad:   # inference only; training stays exact f32
+            key = key + ("bf16",)
         return _QueryFunction.apply(self, key, pts, viewdirs if self.use_viewdirs else None, pts_per_ray,
-                                    self._need_grad(pts), *self._params_in_order())
+                                    need_grad, *self._params_in_order())
 
     # ------------------------------------------------------------------ Keras import (network.py:71-99)
     def load_weights_from_keras(self, weights):

@@ -31,17 +31,8 @@ class NeRF(_StaticNeRF):
             self.pts_layernorms = nn.ModuleList([nn.LayerNorm(W) for _ in range(D)])
             self.views_layernorm = nn.LayerNorm(W // 2)
 
-    def _packed(self, key):
-        pk = self._packed_cache.get(key)
-        if pk is None:
-            params = {k: v for k, v in self.named_parameters() if "layernorm" not in k}
-            if not self.use_viewdirs:
-                params = {k: v for k, v in params.items() if not k.startswith("views_linears")}
-            mode, L, Lv = key
-            pk = ops.PackedNet(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
-                               list(self.skips), self.use_viewdirs, mode=mode, multires=L, multires_views=Lv)
-            self._packed_cache[key] = pk
-        return pk
+    def _pack_params(self):
+        return {k: v for k, v in super()._pack_params().items() if "layernorm" not in k}
 
     def forward(self, x, ts=None):
         if self.use_layernorm:

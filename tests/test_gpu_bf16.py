@@ -1,0 +1,119 @@
+"""bf16 MFMA variant of the fused query (nrf_query_fwd_bf16) against the exact f32 kernel and the reference's
+goldens.  The reference has no bf16 path, so the oracle for it is the f32 result; bar (north star): rendered
+RGB / acc within 1e-2 max-abs.  Raw network outputs are compared relative to their scale."""
+import numpy as np
+import pytest
+import torch
+
+import nerf_fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def load_net(sd, **kw):
+    from nerf_amd.network import NeRF
+    cfg = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    cfg.update(kw)
+    net = NeRF(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net.cuda()
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+
+
+@pytest.mark.parametrize("n_points,ppr", [(64 * 7, 64), (256 * 5 + 192, 1), (33, 33), (65536 + 64, 64)])
+def test_bf16_query_vs_f32(n_points, ppr):
+    net = load_net(fx.make_nerf_state(24))
+    rng = np.random.RandomState(5)
+    pts = dev(rng.uniform(-2.5, 2.5, (n_points, 3)))
+    d = rng.normal(size=(n_points // ppr, 3))
+    dirs = dev(d / np.linalg.norm(d, axis=-1, keepdims=True))
+    with torch.no_grad():
+        ref = net.query_points(pts, dirs, ppr, 10, 4)
+        net.precision = "bf16"
+        out = net.query_points(pts, dirs, ppr, 10, 4)
+        out2 = net.query_points(pts, dirs, ppr, 10, 4)
+    assert torch.equal(out, out2), "bf16 kernel is not deterministic"
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    e = rel_err(host(out), host(ref))
+    assert e < 3e-2, e
+
+
+def test_bf16_small_and_noview_nets():
+    rng = np.random.RandomState(6)
+    pts = dev(rng.uniform(-2, 2, (1000, 3)))
+    kw = dict(D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=[2], use_viewdirs=False)
+    sd = fx.make_nerf_state(23, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,), use_viewdirs=False)
+    net = load_net(sd, **kw)
+    with torch.no_grad():
+        ref = net.query_points(pts, None, 1, 10, 0)
+        net.precision = "bf16"
+        out = net.query_points(pts, None, 1, 10, 0)
+    assert rel_err(host(out), host(ref)) < 3e-2
+    kw = dict(D=3, W=64, input_ch=39, input_ch_views=15, output_ch=4, skips=[1], use_viewdirs=True)
+    sd = fx.make_nerf_state(26, D=3, W=64, input_ch=39, input_ch_views=15, output_ch=4, skips=(1,), use_viewdirs=True)
+    net = load_net(sd, **kw)
+    d = rng.normal(size=(10, 3))
+    dirs = dev(d / np.linalg.norm(d, axis=-1, keepdims=True))
+    with torch.no_grad():
+        ref = net.query_points(pts, dirs, 100, 6, 2)
+        net.precision = "bf16"
+        out = net.query_points(pts, dirs, 100, 6, 2)
+    assert rel_err(host(out), host(ref)) < 3e-2
+
+
+def test_bf16_render_within_1e2(gold):
+    """End to end through render_rays on the well-conditioned nets: 1e-2 max-abs on rgb / acc vs the reference."""
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render_rays, run_network
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    q = lambda i, v, f: run_network(i, v, f, e10, e4, 65536)  # noqa: E731
+    coarse, fine = load_net(fx.make_nerf_state(24)), load_net(fx.make_nerf_state(25))
+    coarse.precision = fine.precision = "bf16"
+    with torch.no_grad():
+        ret = render_rays(dev(gold["rr_smooth_rays"]), coarse, q, 64, retraw=True, perturb=0., N_importance=128,
+                          network_fine=fine, white_bkgd=True)
+    # raw2outputs gives the LAST sample an infinite extent (dists[-1] = 1e10, render.py:98): its alpha is a step
+    # function of sigma's SIGN.  On these random-init nets sigma_last is ~0 for a few rays, where any rounding
+    # (bf16 here) flips acc between ~0 and 1; those rays are excluded from the 1e-2 bar and counted instead.
+    sig_last = {"rgb_map": gold["rr_smooth_raw"][:, -1, 3]}
+    stable = np.abs(sig_last["rgb_map"]) > 2e-3
+    assert stable.mean() > 0.75, stable.mean()
+    for k in ("rgb_map", "acc_map"):
+        np.testing.assert_allclose(host(ret[k])[stable], gold[f"rr_smooth_{k}"][stable], atol=1e-2, rtol=0, err_msg=k)
+    # coarse pass: same rule with the coarse net's own last sigma, taken from an exact f32 query
+    from nerf_amd import ops
+    rays = dev(gold["rr_smooth_rays"])
+    with torch.no_grad():
+        coarse.precision = "fp32"
+        z = ops.sample_coarse(rays, 64)
+        raw0 = q(ops.points(rays, z), rays[:, -3:], coarse)
+    stable0 = np.abs(host(raw0)[:, -1, 3]) > 2e-3
+    assert stable0.mean() > 0.75, stable0.mean()
+    for k in ("rgb0", "acc0"):
+        np.testing.assert_allclose(host(ret[k])[stable0], gold[f"rr_smooth_{k}"][stable0], atol=1e-2, rtol=0, err_msg=k)
+    both = stable & stable0
+    psnr = -10 * np.log10(np.mean((host(ret["rgb_map"])[both] - gold["rr_smooth_rgb_map"][both]) ** 2) + 1e-30)
+    assert psnr > 45.0, psnr
+
+
+def test_bf16_training_uses_f32():
+    """With precision = bf16, a query that needs gradients runs the exact f32 training kernels."""
+    net = load_net(fx.make_nerf_state(24))
+    pts = dev(np.random.RandomState(1).uniform(-1, 1, (64, 3)))
+    dirs = dev(fx.blender_rays(1, 1)[:, -3:])
+    ref = net.query_points(pts, dirs, 64, 10, 4)
+    net.precision = "bf16"
+    out = net.query_points(pts, dirs, 64, 10, 4)
+    assert out.requires_grad and torch.equal(out, ref)
