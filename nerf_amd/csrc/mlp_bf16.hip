@@ -15,6 +15,7 @@
 //     double-angle recurrence (error ~2^-16, far below bf16's 2^-9 rounding of the encoded value).
 // Inference only; training stays on the exact f32 kernels.
 #include "mlp_device.h"
+#include <stdlib.h>
 
 namespace nrf {
 
@@ -56,6 +57,7 @@ struct BfBlock { int32_t type, param, ksteps, col0, ncols; };
 struct BfLayer {
     const float *W, *b;
     int32_t ld, n_out, nt_out, nblk;
+    int32_t tail, pad_;   // the last `tail` k-steps are stored tile-outer ([out tile][k-step]), the rest [k-step][out tile]
     BfBlock blk[3];
     int64_t dst;   // byte offset in the stream
 };
@@ -67,8 +69,10 @@ __global__ void pack_bf16_kernel(BfLayer a, char *stream) {
     const int64_t nthreads = (int64_t)ks_total * a.nt_out * 64;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < nthreads; idx += (int64_t)gridDim.x * blockDim.x) {
         const int lane = idx & 63, frag = (int)(idx >> 6);
-        const int t = frag % a.nt_out;
-        int s = frag / a.nt_out;
+        const int head = (ks_total - a.tail) * a.nt_out;
+        int t, s;
+        if (frag < head) { t = frag % a.nt_out; s = frag / a.nt_out; }
+        else { t = (frag - head) / a.tail; s = ks_total - a.tail + (frag - head) % a.tail; }
         int bi = 0;
         while (s >= a.blk[bi].ksteps) { s -= a.blk[bi].ksteps; ++bi; }
         const BfBlock B = a.blk[bi];
@@ -94,27 +98,35 @@ __global__ void pack_bf16_kernel(BfLayer a, char *stream) {
 }
 
 // ---- host-side stream plan --------------------------------------------------------------------------
+// Stream = the layers in consumption order, each layer's fragments contiguous ([k-step][out tile] order) and
+// each layer padded to a whole number of 16 KiB chunks; then a small f32 table of head biases.
+constexpr int kBiasTable = 64;   // floats
+struct BfBiasEntry { const float *src; int32_t n, dst; };
 struct BfPlan {
-    BfLayer layer[2 * NRF_MAX_D + 8];
-    int n = 0;
+    BfLayer layer[2 * NRF_MAX_D + 12];
+    BfBiasEntry bias[8];
+    int n = 0, nbias = 0;
     int64_t bytes = 0;
-    const char *err = nullptr;
-    void add(const float *W, const float *b, int ld, int n_out, int nt_out, BfBlock b0, BfBlock b1 = {}, BfBlock b2 = {}) {
+    void add(const float *W, const float *b, int ld, int n_out, int nt_out, int tail, BfBlock b0, BfBlock b1 = {}, BfBlock b2 = {}) {
         BfLayer &L = layer[n++];
-        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out;
+        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out; L.tail = tail;
         L.blk[0] = b0; L.blk[1] = b1; L.blk[2] = b2;
         L.nblk = 1 + (b1.type != BFB_NONE) + (b2.type != BFB_NONE);
         L.dst = bytes;
-        int ks = b0.ksteps + b1.ksteps + b2.ksteps;
-        bytes += (int64_t)ks * nt_out * kFrag;
+        int64_t ks = b0.ksteps + b1.ksteps + b2.ksteps;
+        bytes += (ks * nt_out * kFrag + kChunk - 1) / kChunk * kChunk;
     }
+    void add_bias(const float *src, int n_, int dst) { bias[nbias++] = BfBiasEntry{src, n_, dst}; }
 };
 
-constexpr int kBfKsX = 4, kBfKsD = 2, kBfKsT = 2;   // k-steps of the encoded inputs (64 / 32 / 32 slots over both halves)
+constexpr int kBfKsX = 4, kBfKsD = 2, kBfKsT = 2;
+constexpr int kBfTail = 0, kBfTail0 = 0, kBfTail0T = 0;   // (tile-outer layer tails: measured slower)
+// head-bias table slots (per net: +0 canonical net, +32 time net)
+constexpr int kHbOut = 0, kHbAlpha = 8, kHbRgb = 9, kHbTime = 32;
 
 static const char *bf_check_net(const nrf_net_t *net, const nrf_embed_t *emb, bool time_net) {
     if (emb->mode != 0) return "the bf16 kernels take raw points (embed mode 0) only";
-    if (net->W != 64 && net->W != 128 && net->W != 256) return "W must be 64, 128 or 256";
+    if (net->W != 128 && net->W != 256) return "the bf16 kernels are built for W = 128 and 256";
     if (net->D < 1 || net->D > NRF_MAX_D) return "D out of range";
     if (emb->multires < 0 || emb->multires > 10 || net->input_ch != 3 + 6 * emb->multires)
         return "input_ch must equal 3 + 6*multires with multires <= 10";
@@ -131,44 +143,59 @@ static const char *bf_check_net(const nrf_net_t *net, const nrf_embed_t *emb, bo
 }
 
 // Appends one net's layers in the order the kernel consumes them.  time_net: layer 0 reads cat[gamma(x), gamma(t)],
-// the output layer is `out_w` (W -> 3).
+// the output layer is `out_w` (W -> 3).  Hidden layers carry their bias as a 17th k-step (constant-1 channel);
+// layers fed by an encoded input take it from that input's constant slot; the one-tile heads add it on the VALU.
 static void bf_plan_net(BfPlan &P, const nrf_net_t *net, const nrf_embed_t *emb, bool time_net) {
     const int W = net->W, nt = W / 32, ic = net->input_ch, D = net->D;
     const BfBlock X{BFB_PE3, emb->multires, kBfKsX, 0, ic};
-    const BfBlock none{};
+    const BfBlock H{BFB_HIDDEN, 0, 2 * nt, 0, W}, Bi{BFB_BIAS, 0, 1, 0, 0};
     if (time_net)
-        P.add(net->pts_w[0], net->pts_b[0], ic + net->input_ch_views, W, nt, X,
+        P.add(net->pts_w[0], net->pts_b[0], ic + net->input_ch_views, W, nt, kBfTail0T, X,
               BfBlock{BFB_PE1, emb->multires_time, kBfKsT, ic, net->input_ch_views});
     else
-        P.add(net->pts_w[0], net->pts_b[0], ic, W, nt, X);
+        P.add(net->pts_w[0], net->pts_b[0], ic, W, nt, kBfTail0, X);
     for (int i = 1; i < D; ++i) {
         const bool skip = (net->skips_mask >> (i - 1)) & 1;   // network.py:52-53
         if (skip)
-            P.add(net->pts_w[i], net->pts_b[i], W + ic, W, nt, X, BfBlock{BFB_HIDDEN, 0, 2 * nt, ic, W});
+            P.add(net->pts_w[i], net->pts_b[i], W + ic, W, nt, kBfTail, X, BfBlock{BFB_HIDDEN, 0, 2 * nt, ic, W});
         else
-            P.add(net->pts_w[i], net->pts_b[i], W, W, nt, BfBlock{BFB_HIDDEN, 0, 2 * nt, 0, W}, BfBlock{BFB_BIAS, 0, 1, 0, 0});
+            P.add(net->pts_w[i], net->pts_b[i], W, W, nt, kBfTail, H, Bi);
     }
-    const BfBlock H{BFB_HIDDEN, 0, 2 * nt, 0, W}, Bi{BFB_BIAS, 0, 1, 0, 0};
-    if (time_net || !net->use_viewdirs) {
-        P.add(net->out_w, net->out_b, W, time_net ? 3 : net->output_ch, 1, H, Bi);
+    if (time_net) {
+        P.add(net->out_w, net->out_b, W, 3, 1, 0, H);                             // vanilla_dynamic/network.py:305
+        P.add_bias(net->out_b, 3, kHbTime);
         return;
     }
-    P.add(net->alpha_w, net->alpha_b, W, 1, 1, H, Bi);                         // network.py:56
-    P.add(net->feature_w, net->feature_b, W, W, nt, H, Bi);                    // network.py:57
-    P.add(net->views_w, net->views_b, W + net->input_ch_views, W / 2, nt / 2, H,
+    if (!net->use_viewdirs) {
+        P.add(net->out_w, net->out_b, W, net->output_ch, 1, 0, H);                // network.py:67
+        P.add_bias(net->out_b, net->output_ch, kHbOut);
+        return;
+    }
+    P.add(net->alpha_w, net->alpha_b, W, 1, 1, 0, H);                             // network.py:56
+    P.add_bias(net->alpha_b, 1, kHbAlpha);
+    P.add(net->feature_w, net->feature_b, W, W, nt, kBfTail, H, Bi);                    // network.py:57
+    P.add(net->views_w, net->views_b, W + net->input_ch_views, W / 2, nt / 2, kBfTail, H,
           BfBlock{BFB_PE3, emb->multires_views, kBfKsD, W, net->input_ch_views});   // network.py:58-62 (bias: CONST slot)
-    P.add(net->rgb_w, net->rgb_b, W / 2, 3, 1, BfBlock{BFB_HIDDEN, 0, nt, 0, W / 2}, Bi);   // network.py:64
+    P.add(net->rgb_w, net->rgb_b, W / 2, 3, 1, 0, BfBlock{BFB_HIDDEN, 0, nt, 0, W / 2});   // network.py:64
+    P.add_bias(net->rgb_b, 3, kHbRgb);
 }
 
+__global__ void pack_bias_kernel(BfBiasEntry e, float *table) {
+    if ((int)threadIdx.x < e.n) table[e.dst + threadIdx.x] = e.src[threadIdx.x];
+}
+
+static int64_t bf_total_bytes(const BfPlan &P) { return P.bytes + kBiasTable * 4; }
+
 static int bf_pack(const BfPlan &P, void *packed, hipStream_t st) {
+    if (hipMemsetAsync(packed, 0, bf_total_bytes(P), st) != hipSuccess)
+        return nrf::fail(NRF_ERR_LAUNCH, "bf16 pack: hipMemsetAsync failed");
     for (int i = 0; i < P.n; ++i) {
         const BfLayer &L = P.layer[i];
         if (!L.W || !L.b) return nrf::fail(NRF_ERR_INVALID, "bf16 pack: a parameter pointer of the net is null (layer %d)", i);
         hipLaunchKernelGGL(pack_bf16_kernel, dim3(128), dim3(256), 0, st, L, (char *)packed);
     }
-    // tail pad: the loader always copies a full 16 KiB stage
-    if (hipMemsetAsync((char *)packed + P.bytes, 0, kChunk, st) != hipSuccess)
-        return nrf::fail(NRF_ERR_LAUNCH, "bf16 pack: hipMemsetAsync failed");
+    for (int i = 0; i < P.nbias; ++i)
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(1), dim3(64), 0, st, P.bias[i], (float *)((char *)packed + P.bytes));
     return check_launch("nrf_mlp_bf16_pack_weights");
 }
 
@@ -181,82 +208,123 @@ __device__ __forceinline__ uint32_t relu2(uint32_t p) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
 }
 
+// The weight stream as seen by one wave.  LDS holds THREE 16 KiB stages: chunk c is consumed from stage c%3 while
+// chunk c+1 is already complete in the next stage and chunk c+2 is in flight into the third.  Fragments are read
+// kAhead ahead of the MFMA that uses them, across chunk and layer boundaries, so the matrix pipe never waits for
+// an LDS round trip; the one barrier per chunk sits in the MIDDLE of a chunk, where nothing else is pending.
+constexpr int kAhead = 4;
+constexpr int kStages = 3;
 struct WStream {
     __amdgpu_buffer_rsrc_t rsrc;
-    char *lds;           // the workgroup's two stages
-    uint32_t pf_off;     // byte offset (in the stream) of the chunk most recently requested
-    uint32_t cur;        // stage holding the chunk about to be consumed (0 | 1), wave-uniform
-    uint32_t rd;         // this lane's byte offset in `lds` for fragment 0 of the current chunk
+    char *lds;
+    uint32_t total;      // bytes of all chunks (the stream wraps there)
+    uint32_t pf_off;     // stream offset of the next chunk to request
+    uint32_t st_req;     // stage (byte offset in lds) the next request goes to
+    uint32_t rd_cur, rd_nxt;   // this lane's byte offset of fragment 0 in the current / the next chunk's stage
     int lane16, wave;
+    bf16x8 q[kAhead];    // fragments in flight / ready: fragment i of a layer sits in q[i % kAhead]
 
-    __device__ __forceinline__ void request(uint32_t off, uint32_t stage) {
+    __device__ __forceinline__ void request() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t f = (uint32_t)wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + stage * kChunk + f * kFrag),
-                                                     16, lane16, (int)(off + f * kFrag), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + st_req + f * kFrag),
+                                                     16, lane16, (int)(pf_off + f * kFrag), 0, 0);
         }
+        pf_off += kChunk;
+        if (pf_off == total) pf_off = 0;
+        st_req += kChunk;
+        if (st_req == kStages * kChunk) st_req = 0;
     }
-    // Make the next chunk (of `bytes` bytes) current: own copies landed, then the barrier (everyone's copies
-    // landed, everyone is done reading the other stage), then request the chunk after it into that other stage.
-    __device__ __forceinline__ void acquire(uint32_t bytes, bool last) {
+    // Mid-chunk: publish the NEXT chunk (own copies landed -> barrier -> everyone's landed, and everyone is past
+    // the previous chunk, whose stage the request for the chunk after next may now overwrite).
+    __device__ __forceinline__ void publish() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        pf_off = last ? 0u : pf_off + bytes;
-        request(pf_off, cur ^ 1u);
-        rd = (uint32_t)lane16 + cur * kChunk;
-        cur ^= 1u;
+        request();
     }
-    __device__ __forceinline__ bf16x8 frag(int f) const {
-        return *reinterpret_cast<const bf16x8 *>(lds + rd + f * kFrag);
+    __device__ __forceinline__ void rotate() {
+        rd_cur = rd_nxt;
+        rd_nxt += kChunk;
+        if (rd_nxt >= (uint32_t)(kStages * kChunk)) rd_nxt -= kStages * kChunk;
+    }
+    __device__ __forceinline__ bf16x8 read(bool nxt, int f) const {
+        return *reinterpret_cast<const bf16x8 *>(lds + (nxt ? rd_nxt : rd_cur) + f * kFrag);
+    }
+    __device__ __forceinline__ void start() {
+        pf_off = 0; st_req = 0;
+        request();
+        request();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rd_cur = (uint32_t)lane16;
+        rd_nxt = (uint32_t)lane16 + kChunk;
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) q[i] = read(false, i);
     }
 };
 
 // acc[p][t] (+)= W_layer * B(p, s) over the layer's S k-steps; B(p, s) = 8 bf16 of point tile p for k-step s.
-template <int NT_OUT, int S, bool LAST, class BF>
+// The layer's N = S * NT_OUT fragments start on a chunk boundary; N % kAhead == 0 keeps q's phase static.
+template <int NT_OUT, int S, class BF>
 __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st, BF &&B) {
-    constexpr int KC = 16 / NT_OUT;
-    constexpr int NCH = (S + KC - 1) / KC;
+    constexpr int N = S * NT_OUT;
+    static_assert(N % kAhead == 0 && N >= kAhead, "fragment count of a layer must be a multiple of the read-ahead");
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int NCH = (N + 15) / 16;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int ks = (S - c * KC) < KC ? (S - c * KC) : KC;
-        st.acquire((uint32_t)(ks * NT_OUT * kFrag), LAST && c == NCH - 1);
+        const int F = (N - 16 * c) < 16 ? (N - 16 * c) : 16;          // fragments in this chunk
+        const int pos = (F / 2 < F - kAhead) ? F / 2 : F - kAhead;    // publish before the first read of the next chunk
 #pragma unroll
-        for (int s = 0; s < ks; ++s) {
-            const int sg = c * KC + s;
-            const bf16x8 b0 = B(0, sg), b1 = B(1, sg);
-#pragma unroll
-            for (int t = 0; t < NT_OUT; ++t) {
-                const bf16x8 a = st.frag(s * NT_OUT + t);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, sg == 0 ? zero : acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, sg == 0 ? zero : acc[1][t], 0, 0, 0);
+        for (int f = 0; f < F; ++f) {
+            const int i = 16 * c + f;
+            if (f == pos) st.publish();
+            const bf16x8 a = st.q[i % kAhead];
+            {
+                const int j = i + kAhead;
+                if (j < N) st.q[i % kAhead] = st.read((j >> 4) != c, j & 15);
+                else st.q[i % kAhead] = st.read(true, j - N);          // the next layer's first fragments
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const int s = i / NT_OUT, t = i % NT_OUT;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(0, s), s == 0 ? zero : acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(1, s), s == 0 ? zero : acc[1][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        st.rotate();
     }
 }
 
 // accumulators -> next layer's B fragments: k-step 2t+e = registers 8e..8e+7 of tile t, packed pairwise
 template <int NT>
 __device__ __forceinline__ void pack_acts(u32x4v (&hin)[2][2 * NT], const f32x16 (&acc)[2][NT], bool relu) {
+    // One wave per SIMD: a dependent VALU chain (read -> cvt -> max through the same temporaries) issues at a
+    // third of the rate of independent instructions.  So: 16 reads, then 8 converts, then 8 max, pinned in that
+    // order -- every instruction's producer is >= 8 instructions back.
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            float r[16];
+            uint32_t c[8];
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int k = 0; k < 16; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r[k]) : "a"(acc[p][t][k]));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    uint32_t v = pack2(acc[p][t][8 * e + 2 * w], acc[p][t][8 * e + 2 * w + 1]);
-                    hin[p][2 * t + e][w] = relu ? relu2(v) : v;
-                }
+            for (int w = 0; w < 8; ++w) c[w] = pack2(r[2 * w], r[2 * w + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) hin[p][2 * t + (w >> 2)][w & 3] = relu ? relu2(c[w]) : c[w];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 }
 
 // gamma(v) of a 3-vector into KS k-step fragments (slot order of bf_pe3_chan)
 template <int KS>
-__device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float y, float z, int L, int h) {
+__device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float y, float z, int h) {
     constexpr int NF = (8 * KS - 2) / 6;
     float v[8 * KS];
     v[0] = h ? z : x;
@@ -272,7 +340,7 @@ __device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float 
         for (int d = 0; d < 3; ++d) {
             v[2 + 6 * i + d] = s[d];
             v[2 + 6 * i + 3 + d] = c[d];
-            if (i + 1 < NF) {   // two octaves up: angle * 4
+            if (i + 1 < NF) {   // two octaves up: angle * 4  (frequencies >= L meet zero weights)
                 const float s2 = 2.0f * s[d] * c[d], c2 = 1.0f - 2.0f * s[d] * s[d];
                 s[d] = 2.0f * s2 * c2;
                 c[d] = 1.0f - 2.0f * s2 * s2;
@@ -281,7 +349,6 @@ __device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float 
     }
 #pragma unroll
     for (int i = 2 + 6 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
-    (void)L;   // frequencies >= L meet zero weights
 #pragma unroll
     for (int k = 0; k < KS; ++k)
 #pragma unroll
@@ -290,28 +357,27 @@ __device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float 
 
 struct Bf16Args {
     const char *stream;
-    int64_t stream_bytes;    // without the tail pad
+    int64_t stream_bytes;    // all chunks (the head-bias table follows)
     const float *pts, *viewdirs;
     float *raw;
     int64_t n_points;
-    int32_t pts_per_ray, n_trunk, skip_in_mask, use_viewdirs, output_ch, Lx, Ld, pad_;
+    int32_t pts_per_ray, n_trunk, skip_in_mask, use_viewdirs, output_ch, dbg, pad_[2];
 };
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int NT>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a) {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * kChunk];
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     WStream st;
-    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)(a.stream_bytes + kChunk), 0x00020000);
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (a.dbg & 1) ? 0 : (int)a.stream_bytes, 0x00020000);
     st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
     st.lane16 = lane * 16;
     st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    st.pf_off = 0;
-    st.cur = 0;
-    st.rd = 0;
-    st.request(0, 0);
+    st.start();
+    const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
 
     const int64_t ntiles = (a.n_points + 255) >> 8;
     u32x4v one;   // the constant-1 channel of a bias k-step: element 0 of lane half 0
@@ -325,66 +391,68 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
             pp[p] = tile * 256 + st.wave * 64 + p * 32 + n;
             pc[p] = pp[p] < a.n_points ? pp[p] : a.n_points - 1;
             const float *q = a.pts + pc[p] * 3;
-            fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], a.Lx, h);
+            fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], h);
         }
         f32x16 acc[2][NT];
         u32x4v hin[2][2 * NT];
-        gemm_layer<NT, kBfKsX, false>(acc, st, [&](int p, int s) { return as_bf(xin[p][s]); });     // network.py:48-51
+        gemm_layer<NT, kBfKsX>(acc, st, [&](int p, int s) { return as_bf(xin[p][s]); });            // network.py:48-51
         pack_acts<NT>(hin, acc, true);
         for (int l = 1; l < a.n_trunk; ++l) {
             if ((a.skip_in_mask >> l) & 1)                                                        // network.py:52-53
-                gemm_layer<NT, kBfKsX + 2 * NT, false>(acc, st, [&](int p, int s) {
+                gemm_layer<NT, kBfKsX + 2 * NT>(acc, st, [&](int p, int s) {
                     return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
                 });
             else
-                gemm_layer<NT, 2 * NT + 1, false>(acc, st, [&](int p, int s) {
+                gemm_layer<NT, 2 * NT + 1>(acc, st, [&](int p, int s) {
                     return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
                 });
             pack_acts<NT>(hin, acc, true);
         }
         auto Hb = [&](int p, int s) { return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one); };
+        auto Hn = [&](int p, int s) { return as_bf(hin[p][s]); };
         if (a.use_viewdirs) {
-            if constexpr (NT >= 2) {
-                f32x16 acc1[2][1];
-                gemm_layer<1, 2 * NT + 1, false>(acc1, st, Hb);                                    // network.py:56
-                const float alpha0 = acc1[0][0][0], alpha1 = acc1[1][0][0];
-                gemm_layer<NT, 2 * NT + 1, false>(acc, st, Hb);                                    // network.py:57
-                pack_acts<NT>(hin, acc, false);
-                u32x4v din[2][kBfKsD];
+            f32x16 acc1[2][1];
+            gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:56
+            const float ab = hb[kHbAlpha];
+            const float alpha0 = acc1[0][0][0] + ab, alpha1 = acc1[1][0][0] + ab;
+            gemm_layer<NT, 2 * NT + 1>(acc, st, Hb);                                               // network.py:57
+            pack_acts<NT>(hin, acc, false);
+            u32x4v din[2][kBfKsD];
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
-                    fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], a.Ld, h);
-                }
-                f32x16 acc2[2][NT / 2];
-                gemm_layer<NT / 2, 2 * NT + kBfKsD, false>(acc2, st, [&](int p, int s) {          // network.py:58-62
-                    return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
-                });
-                u32x4v hv[2][NT];
-                pack_acts<NT / 2>(hv, acc2, true);
-                gemm_layer<1, NT + 1, true>(acc1, st, [&](int p, int s) {                          // network.py:64
-                    return s < NT ? as_bf(hv[p][s < NT ? s : 0]) : as_bf(one);
-                });
-                if (h == 0) {
-                    if (pp[0] < a.n_points)
-                        reinterpret_cast<float4 *>(a.raw)[pp[0]] = make_float4(acc1[0][0][0], acc1[0][0][1], acc1[0][0][2], alpha0);
-                    if (pp[1] < a.n_points)
-                        reinterpret_cast<float4 *>(a.raw)[pp[1]] = make_float4(acc1[1][0][0], acc1[1][0][1], acc1[1][0][2], alpha1);
-                }
+            for (int p = 0; p < 2; ++p) {
+                const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
+                fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
+            }
+            f32x16 acc2[2][NT / 2];
+            gemm_layer<NT / 2, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {                      // network.py:58-62
+                return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
+            });
+            u32x4v hv[2][NT];
+            pack_acts<NT / 2>(hv, acc2, true);
+            gemm_layer<1, NT>(acc1, st, [&](int p, int s) { return as_bf(hv[p][s]); });            // network.py:64
+            if (h == 0) {
+                const float b0 = hb[kHbRgb], b1 = hb[kHbRgb + 1], b2 = hb[kHbRgb + 2];
+                if (pp[0] < a.n_points)
+                    reinterpret_cast<float4 *>(a.raw)[pp[0]] =
+                        make_float4(acc1[0][0][0] + b0, acc1[0][0][1] + b1, acc1[0][0][2] + b2, alpha0);
+                if (pp[1] < a.n_points)
+                    reinterpret_cast<float4 *>(a.raw)[pp[1]] =
+                        make_float4(acc1[1][0][0] + b0, acc1[1][0][1] + b1, acc1[1][0][2] + b2, alpha1);
             }
         } else {
             f32x16 acc1[2][1];
-            gemm_layer<1, 2 * NT + 1, true>(acc1, st, Hb);                                         // network.py:67
+            gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:67
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 4 * h + r;   // rows 0-3 on lane half 0, 4-7 on half 1 (registers 0..3)
-                    if (o < a.output_ch && pp[p] < a.n_points) a.raw[pp[p] * a.output_ch + o] = acc1[p][0][r];
+                    if (o < a.output_ch && pp[p] < a.n_points) a.raw[pp[p] * a.output_ch + o] = acc1[p][0][r] + hb[kHbOut + o];
                 }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last request must land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests in flight must land before the LDS is released
+    __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace nrf
@@ -396,7 +464,7 @@ extern "C" int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_emb
     if (const char *e = bf_check_net(net, emb, false)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16_packed_bytes: %s", e); return -1; }
     BfPlan P;
     bf_plan_net(P, net, emb, false);
-    return P.bytes + kChunk;
+    return bf_total_bytes(P);
 }
 
 extern "C" int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
@@ -431,14 +499,14 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
     a.skip_in_mask = 0;
     for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
     a.use_viewdirs = net->use_viewdirs; a.output_ch = net->output_ch;
-    a.Lx = emb->multires; a.Ld = emb->multires_views;
+    if (const char *d = getenv("NRF_BF16_DEBUG")) a.dbg = atoi(d);   // timing experiments only (1: drop the weight DMA)
     const int64_t ntiles = (n_points + 255) / 256;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);   // 512 registers per lane: one workgroup per CU
     hipStream_t st = as_stream(stream);
     switch (net->W / 32) {
-        case 8: hipLaunchKernelGGL((query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 8:
+            hipLaunchKernelGGL((query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
         case 4: hipLaunchKernelGGL((query_fwd_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((query_fwd_bf16_kernel<2>), dim3(blocks), dim3(256), 0, st, a); break;
     }
     return check_launch("nrf_query_fwd_bf16");
 }

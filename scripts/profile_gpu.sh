@@ -22,8 +22,14 @@ for what in "$@"; do
         timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_$c" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_render_$c.log" 2>&1
         timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_train_$c" -o train -- python3 $ROOT/bench.py --workload train --steps 1 --warmup 1 > "$OUT/pmc_train_$c.log" 2>&1
       done ;;
-    sq)
-      timeout -s KILL 240 rocprofv3 --pmc $SQ_COUNTERS --output-format csv -d "$OUT/pmc_render_sq" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_render_sq.log" 2>&1 ;;
+    sq)   # SQ_COUNTERS="A B C" (<= 8 SQ counters), EXTRA="--precision bf16" etc.
+      timeout -s KILL 240 rocprofv3 --pmc $SQ_COUNTERS --output-format csv -d "$OUT/pmc_render_sq" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > "$OUT/pmc_render_sq.log" 2>&1 ;;
+    stats_bf16)
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render_bf16" -o render_bf16 -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision bf16 > "$OUT/render_bf16_stats.log" 2>&1 ;;
+    pmc_bf16)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_bf16_$c" -o render_bf16 -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --precision bf16 > "$OUT/pmc_render_bf16_$c.log" 2>&1
+      done ;;
   esac
 done
 for d in "$OUT"/pmc_*/; do [ -d "$d" ] && python3 $ROOT/scripts/pmc_summary.py "$d" > "${d%/}.summary.json"; done

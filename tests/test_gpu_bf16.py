@@ -60,8 +60,8 @@ def test_bf16_small_and_noview_nets():
         net.precision = "bf16"
         out = net.query_points(pts, None, 1, 10, 0)
     assert rel_err(host(out), host(ref)) < 3e-2
-    kw = dict(D=3, W=64, input_ch=39, input_ch_views=15, output_ch=4, skips=[1], use_viewdirs=True)
-    sd = fx.make_nerf_state(26, D=3, W=64, input_ch=39, input_ch_views=15, output_ch=4, skips=(1,), use_viewdirs=True)
+    kw = dict(D=3, W=128, input_ch=39, input_ch_views=15, output_ch=4, skips=[1], use_viewdirs=True)
+    sd = fx.make_nerf_state(26, D=3, W=128, input_ch=39, input_ch_views=15, output_ch=4, skips=(1,), use_viewdirs=True)
     net = load_net(sd, **kw)
     d = rng.normal(size=(10, 3))
     dirs = dev(d / np.linalg.norm(d, axis=-1, keepdims=True))
@@ -70,6 +70,12 @@ def test_bf16_small_and_noview_nets():
         net.precision = "bf16"
         out = net.query_points(pts, dirs, 100, 6, 2)
     assert rel_err(host(out), host(ref)) < 3e-2
+    # W = 64 has no bf16 kernel: asking for it fails loudly instead of silently running something else
+    kw = dict(D=2, W=64, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    net = load_net(fx.make_nerf_state(27, D=2, W=64, input_ch=63, input_ch_views=27, output_ch=4, skips=(4,)), **kw)
+    net.precision = "bf16"
+    with torch.no_grad(), pytest.raises(RuntimeError, match="W = 128 and 256"):
+        net.query_points(pts, dirs, 100, 10, 4)
 
 
 def test_bf16_render_within_1e2(gold):
