@@ -15,7 +15,7 @@ FLOP_PER_POINT = 2 * (TIME_MAC + OCC_MAC)
 def run_dnerf(args, torch, dist, world, rank, device):
     import nerf_fixtures as fx
     import nerf_amd.vanilla_dynamic as vd
-    from bench import PEAK_F32_MFMA_TFLOPS
+    from bench import PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS
     from nerf_amd import parallel
     from nerf_amd.rays import get_rays
 
@@ -28,6 +28,9 @@ def run_dnerf(args, torch, dist, world, rank, device):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(device)
     model.embed_fn = embed_fn
+    model.precision = args.precision
+    bf16 = args.precision == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
     kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
               white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
@@ -89,14 +92,15 @@ def run_dnerf(args, torch, dist, world, rank, device):
             "metric": "rays/sec at 64+128 samples/ray (D-NeRF deformation render)",
             "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"D-NeRF bouncingballs-shaped {H}x{W} view, deformation network (time net D=8 W=256 -> "
-                                   "dx -> canonical net D=8 W=256), 64+128 samples, one model for both passes, fp32",
+                                   f"dx -> canonical net D=8 W=256), 64+128 samples, one model for both passes, {args.precision}",
                        "rays_per_step": H * W,
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "dnerf_query_fwd_kernel<8> (gamma(x), gamma(t), time net, re-embed, canonical net)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": ("dnerf_query_fwd_bf16_kernel<8>" if bf16 else "dnerf_query_fwd_kernel<8>")
+                         + " (gamma(x), gamma(t), time net, re-embed, canonical net)",
                          "launches": len(events), "avg_launch_ms": q_ms / max(len(events), 1),
                          "flop_per_point": FLOP_PER_POINT, "query_share_of_step": q_ms * 1e-3 / dt},
         }

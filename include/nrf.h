@@ -134,6 +134,16 @@ int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void
 int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
                        const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
 
+/* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
+ * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */
+int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb);
+int nrf_dnerf_bf16_pack_weights(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                void *packed, void *stream);
+int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                             const void *packed, const float *pts, const float *viewdirs, const float *times,
+                             int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
+                             int32_t zero_canonical, float *raw, float *dx, void *stream);
+
 /* K4  raw2outputs -- render.py:82-131.  raw [N,S,4], z_vals [N,S], rays_d rows of `d_stride` floats
  * (pass rays+3 with d_stride = ncol to read directions out of the ray matrix), noise NULL or [N,S]
  * (already multiplied by raw_noise_std).  Outputs rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]. */

@@ -355,6 +355,63 @@ __device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float 
         for (int w = 0; w < 4; ++w) out[k][w] = pack2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
 }
 
+__device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Trunk of one net (network.py:48-53): layer 0 on S0 encoded k-steps B0(p, s), then the hidden layers, each followed
+// by the conversion of its outputs into the next layer's B fragments.
+template <int NT, int S0, class B0>
+__device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v (&xin)[2][kBfKsX],
+                                         const u32x4v &one, WStream &st, int n_trunk, int skip_in_mask, B0 &&b0) {
+    gemm_layer<NT, S0>(acc, st, b0);
+    pack_acts<NT>(hin, acc, true);
+    for (int l = 1; l < n_trunk; ++l) {
+        if ((skip_in_mask >> l) & 1)
+            gemm_layer<NT, kBfKsX + 2 * NT>(acc, st, [&](int p, int s) {
+                return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
+            });
+        else
+            gemm_layer<NT, 2 * NT + 1>(acc, st, [&](int p, int s) {
+                return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
+            });
+        pack_acts<NT>(hin, acc, true);
+    }
+}
+
+// View-direction head of the canonical net (network.py:56-65) -> (rgb + alpha) of both point tiles, stored by lane half 0.
+template <int NT>
+__device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v &one, WStream &st,
+                                              const float *hb, const float *viewdirs, const int64_t (&pp)[2],
+                                              const int64_t (&pc)[2], int64_t n_points, int pts_per_ray, int h, float *raw) {
+    auto Hb = [&](int p, int s) { return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one); };
+    auto Hn = [&](int p, int s) { return as_bf(hin[p][s]); };
+    f32x16 acc1[2][1];
+    gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:56
+    const float ab = hb[kHbAlpha];
+    const float alpha0 = acc1[0][0][0] + ab, alpha1 = acc1[1][0][0] + ab;
+    gemm_layer<NT, 2 * NT + 1>(acc, st, Hb);                                               // network.py:57
+    pack_acts<NT>(hin, acc, false);
+    u32x4v din[2][kBfKsD];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float *d = viewdirs + (pc[p] / pts_per_ray) * 3;
+        fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
+    }
+    f32x16 acc2[2][NT / 2];
+    gemm_layer<NT / 2, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {                      // network.py:58-62
+        return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
+    });
+    u32x4v hv[2][NT];
+    pack_acts<NT / 2>(hv, acc2, true);
+    gemm_layer<1, NT>(acc1, st, [&](int p, int s) { return as_bf(hv[p][s]); });            // network.py:64
+    if (h == 0) {
+        const float b0 = hb[kHbRgb], b1 = hb[kHbRgb + 1], b2 = hb[kHbRgb + 2];
+        if (pp[0] < n_points)
+            reinterpret_cast<float4 *>(raw)[pp[0]] = make_float4(acc1[0][0][0] + b0, acc1[0][0][1] + b1, acc1[0][0][2] + b2, alpha0);
+        if (pp[1] < n_points)
+            reinterpret_cast<float4 *>(raw)[pp[1]] = make_float4(acc1[1][0][0] + b0, acc1[1][0][1] + b1, acc1[1][0][2] + b2, alpha1);
+    }
+}
+
 struct Bf16Args {
     const char *stream;
     int64_t stream_bytes;    // all chunks (the head-bias table follows)
@@ -364,7 +421,6 @@ struct Bf16Args {
     int32_t pts_per_ray, n_trunk, skip_in_mask, use_viewdirs, output_ch, dbg, pad_[2];
 };
 
-__device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int NT>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a) {
@@ -395,53 +451,13 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
         }
         f32x16 acc[2][NT];
         u32x4v hin[2][2 * NT];
-        gemm_layer<NT, kBfKsX>(acc, st, [&](int p, int s) { return as_bf(xin[p][s]); });            // network.py:48-51
-        pack_acts<NT>(hin, acc, true);
-        for (int l = 1; l < a.n_trunk; ++l) {
-            if ((a.skip_in_mask >> l) & 1)                                                        // network.py:52-53
-                gemm_layer<NT, kBfKsX + 2 * NT>(acc, st, [&](int p, int s) {
-                    return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
-                });
-            else
-                gemm_layer<NT, 2 * NT + 1>(acc, st, [&](int p, int s) {
-                    return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
-                });
-            pack_acts<NT>(hin, acc, true);
-        }
-        auto Hb = [&](int p, int s) { return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one); };
-        auto Hn = [&](int p, int s) { return as_bf(hin[p][s]); };
+        bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.n_trunk, a.skip_in_mask,
+                             [&](int p, int s) { return as_bf(xin[p][s]); });                     // network.py:48-53
         if (a.use_viewdirs) {
-            f32x16 acc1[2][1];
-            gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:56
-            const float ab = hb[kHbAlpha];
-            const float alpha0 = acc1[0][0][0] + ab, alpha1 = acc1[1][0][0] + ab;
-            gemm_layer<NT, 2 * NT + 1>(acc, st, Hb);                                               // network.py:57
-            pack_acts<NT>(hin, acc, false);
-            u32x4v din[2][kBfKsD];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
-                fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
-            }
-            f32x16 acc2[2][NT / 2];
-            gemm_layer<NT / 2, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {                      // network.py:58-62
-                return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
-            });
-            u32x4v hv[2][NT];
-            pack_acts<NT / 2>(hv, acc2, true);
-            gemm_layer<1, NT>(acc1, st, [&](int p, int s) { return as_bf(hv[p][s]); });            // network.py:64
-            if (h == 0) {
-                const float b0 = hb[kHbRgb], b1 = hb[kHbRgb + 1], b2 = hb[kHbRgb + 2];
-                if (pp[0] < a.n_points)
-                    reinterpret_cast<float4 *>(a.raw)[pp[0]] =
-                        make_float4(acc1[0][0][0] + b0, acc1[0][0][1] + b1, acc1[0][0][2] + b2, alpha0);
-                if (pp[1] < a.n_points)
-                    reinterpret_cast<float4 *>(a.raw)[pp[1]] =
-                        make_float4(acc1[1][0][0] + b0, acc1[1][0][1] + b1, acc1[1][0][2] + b2, alpha1);
-            }
+            bf_views_head<NT>(acc, hin, one, st, hb, a.viewdirs, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
         } else {
             f32x16 acc1[2][1];
-            gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:67
+            gemm_layer<1, 2 * NT>(acc1, st, [&](int p, int s) { return as_bf(hin[p][s]); });       // network.py:67
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -455,9 +471,178 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
     __builtin_amdgcn_s_barrier();
 }
 
+// gamma(t) of a scalar into KS k-step fragments (slot order of bf_pe1_chan)
+template <int KS>
+__device__ __forceinline__ void fill_pe1_bf16(u32x4v (&out)[KS], float t, int h) {
+    constexpr int NF = (8 * KS - 1) / 2;
+    float v[8 * KS];
+    v[0] = h ? 0.0f : t;
+    float s, c;
+    sincosf(t * pow2i(h), &s, &c);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        v[1 + 2 * i] = s;
+        v[2 + 2 * i] = c;
+        if (i + 1 < NF) {
+            const float s2 = 2.0f * s * c, c2 = 1.0f - 2.0f * s * s;
+            s = 2.0f * s2 * c2;
+            c = 1.0f - 2.0f * s2 * s2;
+        }
+    }
+#pragma unroll
+    for (int i = 1 + 2 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) out[k][w] = pack2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
+}
+
+struct DnerfBf16Args {
+    const char *stream;           // time net layers, canonical net layers, head-bias table
+    int64_t stream_bytes;
+    const float *pts, *viewdirs, *times;
+    float *raw, *dx;
+    int64_t n_points, netchunk;
+    int32_t pts_per_ray, t_div, zero_canonical;
+    int32_t t_trunk, t_skip_mask, c_trunk, c_skip_mask, pad_;
+};
+
+// K6 in bf16: dx = time_net(gamma(x), gamma(t)); raw = occ_net(gamma(x + dx), gamma(d)) -- vanilla_dynamic/network.py:307-341.
+// dx and x + dx stay in f32; only the MLP operands are bf16.  With t == 0 for a whole netchunk (network.py:315-322) the
+// time net still runs here (the weight stream is one fixed sequence) and its dx is replaced by zero.
+template <int NT>
+__global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const DnerfBf16Args a) {
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    WStream st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
+    st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.start();
+    const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
+    const int64_t ntiles = (a.n_points + 255) >> 8;
+    u32x4v one;
+    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t pp[2], pc[2];
+        float px[2][3];
+        bool skip[2];
+        u32x4v xin[2][kBfKsX], tin[2][kBfKsT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pp[p] = tile * 256 + st.wave * 64 + p * 32 + n;
+            pc[p] = pp[p] < a.n_points ? pp[p] : a.n_points - 1;
+            const float *q = a.pts + pc[p] * 3;
+            px[p][0] = q[0]; px[p][1] = q[1]; px[p][2] = q[2];
+            const int64_t chunk_first = (pc[p] / a.netchunk) * a.netchunk;       // network.py:315-322
+            skip[p] = a.zero_canonical && a.times[chunk_first / a.t_div] == 0.0f;
+            fill_pe3_bf16<kBfKsX>(xin[p], px[p][0], px[p][1], px[p][2], h);
+            fill_pe1_bf16<kBfKsT>(tin[p], a.times[pc[p] / a.t_div], h);
+        }
+        f32x16 acc[2][NT];
+        u32x4v hin[2][2 * NT];
+        bf_trunk<NT, kBfKsX + kBfKsT>(acc, hin, xin, one, st, a.t_trunk, a.t_skip_mask, [&](int p, int s) {
+            return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(tin[p][s >= kBfKsX ? s - kBfKsX : 0]);
+        });
+        {
+            f32x16 acc1[2][1];
+            gemm_layer<1, 2 * NT>(acc1, st, [&](int p, int s) { return as_bf(hin[p][s]); });       // network.py:305
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float d[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // rows 0..2 sit in registers 0..2 of lane half 0; the other half needs them too (it encodes the
+                    // odd frequencies of the same point)
+                    d[k] = __shfl(acc1[p][0][k] + hb[kHbTime + k], n);
+                    if (skip[p]) d[k] = 0.0f;
+                    px[p][k] += d[k];                                                             // network.py:331
+                }
+                if (h == 0 && pp[p] < a.n_points) {
+                    a.dx[pp[p] * 3 + 0] = d[0]; a.dx[pp[p] * 3 + 1] = d[1]; a.dx[pp[p] * 3 + 2] = d[2];
+                }
+                fill_pe3_bf16<kBfKsX>(xin[p], px[p][0], px[p][1], px[p][2], h);                   // network.py:332-333
+            }
+        }
+        bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.c_trunk, a.c_skip_mask, [&](int p, int s) { return as_bf(xin[p][s]); });
+        bf_views_head<NT>(acc, hin, one, st, hb, a.viewdirs, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace nrf
 
 using namespace nrf;
+
+static int skip_in_mask_of(const nrf_net_t *net) {
+    int m = 0;
+    for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) m |= 1 << i;
+    return m;
+}
+
+static const char *bf_check_dnerf(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb) {
+    if (const char *e = bf_check_net(time_net, emb, true)) return e;
+    if (const char *e = bf_check_net(occ_net, emb, false)) return e;
+    if (!occ_net->use_viewdirs) return "the canonical net must use view directions";
+    if (time_net->W != occ_net->W) return "time and canonical nets must have the same width";
+    return nullptr;
+}
+
+extern "C" int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb) {
+    if (!time_net || !occ_net || !emb) return -1;
+    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_bf16_packed_bytes: %s", e); return -1; }
+    BfPlan P;
+    bf_plan_net(P, time_net, emb, true);
+    bf_plan_net(P, occ_net, emb, false);
+    return bf_total_bytes(P);
+}
+
+extern "C" int nrf_dnerf_bf16_pack_weights(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                           void *packed, void *stream) {
+    NRF_REQUIRE(time_net && occ_net && emb && packed, "nrf_dnerf_bf16_pack_weights: null pointer");
+    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_bf16_pack_weights: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nrf_dnerf_bf16_pack_weights: packed must be 16-byte aligned");
+    BfPlan P;
+    bf_plan_net(P, time_net, emb, true);
+    bf_plan_net(P, occ_net, emb, false);
+    return bf_pack(P, packed, as_stream(stream));
+}
+
+extern "C" int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                        const void *packed, const float *pts, const float *viewdirs, const float *times,
+                                        int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
+                                        int32_t zero_canonical, float *raw, float *dx, void *stream) {
+    NRF_REQUIRE(time_net && occ_net && emb && packed && pts && viewdirs && times && raw && dx,
+                "nrf_dnerf_query_fwd_bf16: null pointer");
+    NRF_REQUIRE(n_points >= 0 && pts_per_ray >= 1 && netchunk >= 1, "nrf_dnerf_query_fwd_bf16: bad sizes");
+    NRF_REQUIRE(n_points % pts_per_ray == 0, "nrf_dnerf_query_fwd_bf16: n_points must be a multiple of pts_per_ray");
+    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_query_fwd_bf16: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
+                "nrf_dnerf_query_fwd_bf16: packed and raw must be 16-byte aligned");
+    if (n_points == 0) return NRF_OK;
+    BfPlan P;
+    bf_plan_net(P, time_net, emb, true);
+    bf_plan_net(P, occ_net, emb, false);
+    DnerfBf16Args a{};
+    a.stream = (const char *)packed; a.stream_bytes = P.bytes;
+    a.pts = pts; a.viewdirs = viewdirs; a.times = times; a.raw = raw; a.dx = dx;
+    a.n_points = n_points; a.netchunk = netchunk; a.pts_per_ray = pts_per_ray;
+    a.t_div = times_per_point ? 1 : pts_per_ray; a.zero_canonical = zero_canonical;
+    a.t_trunk = time_net->D; a.t_skip_mask = skip_in_mask_of(time_net);
+    a.c_trunk = occ_net->D; a.c_skip_mask = skip_in_mask_of(occ_net);
+    const int64_t ntiles = (n_points + 255) / 256;
+    const int blocks = (int)(ntiles < 256 ? ntiles : 256);
+    hipStream_t st = as_stream(stream);
+    switch (occ_net->W / 32) {
+        case 8: hipLaunchKernelGGL((dnerf_query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((dnerf_query_fwd_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, a); break;
+    }
+    return check_launch("nrf_dnerf_query_fwd_bf16");
+}
 
 extern "C" int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
     if (!net || !emb) return -1;

@@ -121,9 +121,15 @@ class DNeRF_Deformation(nn.Module):
             if use_layernorm else None
         self._packed_time = None
         self._time_versions = None
+        self._packed_bf16 = None
+        self._bf16_versions = None
+        # "fp32" (the reference's arithmetic) or "bf16" (bf16 MFMA, f32 accumulate, inference only); an attribute,
+        # not a constructor argument of the reference
+        self.precision = "fp32"
 
     def _apply(self, fn, *args, **kwargs):
         self._packed_time = None
+        self._packed_bf16 = None
         return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------ fused path
@@ -155,6 +161,45 @@ class DNeRF_Deformation(nn.Module):
                    "nrf_dnerf_pack_time_weights")
         self._time_versions = vers
 
+    def _time_params(self):
+        return [p for l in self._time for p in (l.weight, l.bias)] + [self._time_out.weight, self._time_out.bias]
+
+    def _fill_time_pointers(self, n, keep):
+        for i in range(self.D_deform):
+            n.pts_w[i] = C.c_void_p(keep[2 * i].data_ptr())
+            n.pts_b[i] = C.c_void_p(keep[2 * i + 1].data_ptr())
+        n.out_w, n.out_b = C.c_void_p(keep[-2].data_ptr()), C.c_void_p(keep[-1].data_ptr())
+
+    def _query_points_bf16(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, L, Lv, Lt):
+        """nrf_dnerf_query_fwd_bf16: one bf16 weight stream for both nets."""
+        lib = _lib.lib()
+        occ = self._occ._packed((0, L, Lv))          # its descriptor carries the canonical net's f32 parameter pointers
+        occ._fill_pointers()
+        tn, e = self._time_desc(L, Lt)
+        e.multires_views = Lv
+        tparams = self._time_params()
+        keep = [ops._f32(p.detach(), "time-net parameter") for p in tparams]
+        self._fill_time_pointers(tn, keep)
+        vers = (L, Lv, Lt) + tuple((p.data_ptr(), p._version) for p in tparams + list(self._occ.parameters()))
+        if self._packed_bf16 is None or vers != self._bf16_versions:
+            nb = lib.nrf_dnerf_bf16_packed_bytes(C.byref(tn), C.byref(occ.net), C.byref(e))
+            if nb <= 0:
+                raise RuntimeError("nrf_dnerf_bf16_packed_bytes: " + lib.nrf_last_error_string().decode())
+            if self._packed_bf16 is None or self._packed_bf16.numel() != nb:
+                self._packed_bf16 = torch.empty((nb,), device=keep[0].device, dtype=torch.uint8)
+            _lib.check(lib.nrf_dnerf_bf16_pack_weights(C.byref(tn), C.byref(occ.net), C.byref(e),
+                                                       ops._ptr(self._packed_bf16), ops._stream()),
+                       "nrf_dnerf_bf16_pack_weights")
+            self._bf16_versions = vers
+        P = pts.shape[0]
+        raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
+        dx = torch.empty((P, 3), device=pts.device, dtype=torch.float32)
+        _lib.check(lib.nrf_dnerf_query_fwd_bf16(
+            C.byref(tn), C.byref(occ.net), C.byref(e), ops._ptr(self._packed_bf16), ops._ptr(pts), ops._ptr(viewdirs),
+            ops._ptr(times), P, int(pts_per_ray), int(bool(times_per_point)), int(netchunk),
+            int(bool(self.zero_canonical)), ops._ptr(raw), ops._ptr(dx), ops._stream()), "nrf_dnerf_query_fwd_bf16")
+        return raw, dx
+
     def query_points(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires, multires_views,
                      multires_time):
         """Fused deformation chain on raw inputs: pts [P,3], viewdirs [P/pts_per_ray,3], times [P] or
@@ -164,13 +209,16 @@ class DNeRF_Deformation(nn.Module):
                                       "(run under torch.no_grad() to render)")
         if self.use_layernorm or not self.use_viewdirs:
             raise RuntimeError("nerf_amd: the fused deformation kernel needs use_viewdirs=True, use_layernorm=False")
+        pts, viewdirs = ops._f32(pts, "pts"), ops._f32(viewdirs, "viewdirs")
+        times = ops._f32(times, "times").reshape(-1)
+        if self.precision == "bf16":
+            return self._query_points_bf16(pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires,
+                                           multires_views, multires_time)
         self._refresh_time(multires, multires_time)
         occ = self._occ._packed((0, multires, multires_views))
         occ.refresh()
         tn, e = self._time_desc(multires, multires_time)
         e.multires_views = multires_views
-        pts, viewdirs = ops._f32(pts, "pts"), ops._f32(viewdirs, "viewdirs")
-        times = ops._f32(times, "times").reshape(-1)
         P = pts.shape[0]
         raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
         dx = torch.empty((P, 3), device=pts.device, dtype=torch.float32)

@@ -172,3 +172,32 @@ def test_layernorm_variant_runs(parts):
         raw, dx = vd.run_network_dnerf(pts, dev(fx.blender_rays(3, 1)[:, -3:]), torch.full((3, 1), 0.3, device="cuda"),
                                        m, embed_fn, embeddirs_fn, embed_time)
     assert raw.shape == (3, 8, 4) and dx.shape == (3, 8, 3) and torch.isfinite(raw).all()
+
+
+def test_bf16_deformation_chain(gold_dnerf, parts):
+    """nrf_dnerf_query_fwd_bf16 against the exact f32 kernel on the same model: dx within 1e-2 of its scale.  The
+    canonical net then sees x + dx through a frequency-512 encoding, so raw is compared where it is well-conditioned:
+    on a smooth (default-init, dx_scale 1) model."""
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                 input_ch_time=21, output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    sd = fx.make_dnerf_state(33, peaky=False, dx_scale=1.0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    rng = np.random.RandomState(3)
+    pts = dev(rng.uniform(-1.5, 1.5, (6, 64, 3)))
+    dirs = dev(fx.blender_rays(6, 2)[:, -3:])
+    times = dev(np.array([[0.0], [0.5], [0.25], [1.0], [0.7], [0.1]]))
+    run = lambda nc: vd.run_network_dnerf(pts, dirs, times, model, embed_fn, embeddirs_fn, embed_time, netchunk=nc)  # noqa: E731
+    with torch.no_grad():
+        raw_ref, dx_ref = run(64)
+        model.precision = "bf16"
+        raw, dx = run(64)
+        raw_b, dx_b = run(64)
+    assert torch.equal(raw, raw_b) and torch.equal(dx, dx_b)
+    assert float(dx[0].abs().max()) == 0.0 and float(dx_ref[0].abs().max()) == 0.0     # t == 0 chunk: no deformation
+    sc = float(dx_ref.abs().max())
+    assert float((dx - dx_ref).abs().max()) < 1e-2 * max(sc, 1e-3), (float((dx - dx_ref).abs().max()), sc)
+    rs = float(raw_ref.abs().max())
+    assert float((raw - raw_ref).abs().max()) < 3e-2 * rs, (float((raw - raw_ref).abs().max()), rs)
