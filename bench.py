@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- rays/sec of the NeRF per-ray rendering path at 64 coarse + 128 fine samples per ray.
 
-    python bench.py --gpus N --steps K --warmup W [--workload render|train|dnerf] [--size 800]
+    python bench.py --gpus N --steps K --warmup W [--workload render|fern|train|dnerf] [--precision fp32|bf16] [--size 800]
 
 A step = one full render of a synthetic 800x800 view (BASELINE.json configs[1]: D=8/W=256 coarse+fine
 nets, multires 10/4, view directions, white background, near/far 2/6, chunk 32768, perturb=0) through
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="render", choices=["render", "train", "dnerf"])
+    ap.add_argument("--workload", default="render", choices=["render", "fern", "train", "dnerf"])
     ap.add_argument("--size", type=int, default=800, help="image side (render workload)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
@@ -202,20 +202,31 @@ def main():
               raw_noise_std=0., ndc=False, lindisp=False)
     H = W = args.size
     K, _ = fx.intrinsics(H, W)
+    fern = args.workload == "fern"
+    if fern:   # BASELINE.json configs[3]: LLFF fern at factor 4, NDC rays, forward-facing pose, no white background
+        H, W = 756, 1008
+        K = np.array([[815.0, 0, 0.5 * W], [0, 815.0, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+        kw.update(ndc=True, white_bkgd=False)
+    near, far = (0., 1.) if fern else (2., 6.)
     timer = QueryTimer(torch)
     timer.install()
 
     def step(i):
-        c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
+        if fern:   # identity rotation, small lateral motion per step
+            c2w = torch.eye(4)[:3, :4].clone()
+            c2w[0, 3] = 0.02 * i
+            c2w = c2w.to(device)
+        else:
+            c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
         with torch.no_grad():
             if world == 1:
-                rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=2., far=6., **kw)
+                rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=near, far=far, **kw)
                 return rgb
             ro_full, rd_full = get_rays(H, W, K, c2w)
 
             def rows(row0, nrows):
                 rays = torch.stack([ro_full[row0:row0 + nrows].reshape(-1, 3), rd_full[row0:row0 + nrows].reshape(-1, 3)])
-                rgb, disp, acc, _ = render(H, W, K, chunk=32768, rays=rays, near=2., far=6., **kw)
+                rgb, disp, acc, _ = render(H, W, K, chunk=32768, rays=rays, near=near, far=far, **kw)
                 return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
             return parallel.render_sharded(rows, H, W, rank, world)
 
@@ -256,8 +267,8 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"lego-shaped {H}x{W} test-view render, 64+128 samples, D=8 W=256 coarse+fine, "
-                                   f"{args.precision}, chunk 32768", "rays_per_step": n_rays,
+            "config": {"workload": (f"LLFF-fern-shaped {W}x{H} NDC render" if fern else f"lego-shaped {H}x{W} test-view render")
+                       + f", 64+128 samples, D=8 W=256 coarse+fine, {args.precision}, chunk 32768", "rays_per_step": n_rays,
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
