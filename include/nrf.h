@@ -105,6 +105,12 @@ int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *pac
                   const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                   void *stream);
 
+/* nrf_query_bwd that ALSO returns d(loss)/d(pts) [P,3] -- needed when the query points depend on parameters, as in
+ * the D-NeRF chain x + dx (vanilla_dynamic/network.py:331-339; autograd through embed_fn).  Embed mode 0 only. */
+int nrf_query_bwd_input(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                        const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                        const float *pts, float *g_pts, void *stream);
+
 /* ---- D-NeRF deformation chain (vanilla_dynamic/) ----
  * The time ("deformation") net of DNeRF_Deformation (vanilla_dynamic/network.py:254-305) is described with
  * nrf_net_t as: pts_w/pts_b = the `_time` layers, out_w/out_b = `_time_out` (W -> 3), input_ch = position
@@ -133,6 +139,20 @@ int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
 int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
 int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
                        const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
+
+/* D-NeRF training (autograd of vanilla_dynamic/network.py:307-341, the loss.backward() of vanilla_dynamic/train.py):
+ *   forward : dx  = nrf_dnerf_time_fwd_train(time net; saves acts_t);   x' = x + dx   (caller; dx := 0 where the
+ *             reference's t == 0 shortcut applies);   raw = nrf_query_fwd_train(canonical net, x'; saves acts_c)
+ *   backward: nrf_query_bwd_input(canonical net, g_raw) -> canonical parameter grads + g_x';
+ *             nrf_dnerf_time_bwd(time net, g_dx = g_x' [+ d(loss)/d(dx)]) -> time-net parameter grads.
+ * `grads` of nrf_dnerf_time_bwd uses the time-net descriptor layout (pts_w/pts_b = _time layers, out_w/out_b = _time_out).
+ * Workspace sizes: nrf_train_acts_floats / nrf_train_grads_floats / nrf_train_slab_floats with the same descriptor. */
+int nrf_dnerf_time_fwd_train(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time, const float *pts,
+                             const float *times, int64_t n_points, int32_t pts_per_ray, int32_t times_per_point,
+                             float *dx, float *acts, void *stream);
+int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time, const float *g_dx,
+                       const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                       void *stream);
 
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */

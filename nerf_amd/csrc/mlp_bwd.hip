@@ -115,7 +115,7 @@ struct DgradArgs {
     int64_t n_points;
 };
 
-template <int NT>
+template <int NT, bool GX = false>
 __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
     const NetPlan &pl = a.plan;
     const TrainLayout &tl = a.tl;
@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
         TBuf ta = make_tbuf(const_cast<float *>(a.acts) + tile * tl.a_tile, tl.a_tile, lane);
         TBuf tg = make_tbuf(a.gbuf + tile * tl.g_tile, tl.g_tile, lane);
         f32x16 g[NT], nx[NT];
+        f32x16 gx[2];   // GX: d/d(gamma(x)), 64 channels in the reference's order, summed over the layers that read it
+        int xi = __builtin_popcount(((unsigned)pl.skip_in_mask | 1u) & ((1u << pl.n_trunk) - 1u));
+        if constexpr (GX) zero_acc<2>(gx);
         zero_acc<NT>(g);
         if (pl.use_viewdirs) {
             if constexpr (NT >= 2) {
@@ -173,13 +176,44 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
         for (int l = pl.n_trunk - 1; l >= 0; --l) {
             relu_mask_t8<NT>(ta, (uint32_t)tl.a_trunk + l * (32 * W), g);
             store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk + l * (32 * W), W, g);
+            if constexpr (GX) {
+                if (l == 0 || ((pl.skip_in_mask >> l) & 1)) {   // g_x += W_l[:, :input_ch]^T g_l
+                    --xi;
+                    gemm_hid<NT, 2>(gx, g, wb, (uint32_t)(pl.xT_base + (int64_t)xi * pl.xT_stride));
+                }
+            }
             if (l > 0) {
                 zero_acc<NT>(nx);
                 gemm_hid<NT, NT>(nx, g, wb, (uint32_t)(pl.trunkT_base + (int64_t)(l - 1) * pl.trunkT_stride));
                 relu_move<NT>(g, nx, false);
             }
         }
+        if constexpr (GX) store_acc_t8c<2>(tg, (uint32_t)tl.g_xin, 64, gx);
     }
+}
+
+// d(loss)/d(x) from d(loss)/d(gamma(x)) (positional_encoding.py:24-33 differentiated): channel 3+6f+d is
+// sin(2^f x_d), 3+6f+3+d is cos(2^f x_d).  One thread per point; reads the point's 64-channel column of the T8 section.
+__global__ void __launch_bounds__(256) pe3_bwd_t8_kernel(const float *gbuf, int64_t g_tile, int64_t g_sec, const float *pts,
+                                                         int L, int64_t n_points, float *g_pts) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= n_points) return;
+    const int q = (int)(p & 31);
+    const float *g = gbuf + (p >> 5) * g_tile + g_sec + ((q >> 3) * 64) * 8 + (q & 7);   // channel c at g[c * 8]
+    float out[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float x = pts[p * 3 + d];
+        float acc = g[d * 8];
+        for (int f = 0; f < L; ++f) {
+            const float sc = pow2i(f);
+            float sn, cs;
+            sincosf(x * sc, &sn, &cs);
+            acc += sc * (cs * g[(3 + 6 * f + d) * 8] - sn * g[(3 + 6 * f + 3 + d) * 8]);
+        }
+        out[d] = acc;
+    }
+    g_pts[p * 3 + 0] = out[0]; g_pts[p * 3 + 1] = out[1]; g_pts[p * 3 + 2] = out[2];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,15 +407,23 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
     return nchunks * (np * kp + np);
 }
 
-extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
-                             const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
-                             void *stream) {
+// time_ch > 0: `net` describes a deformation ("time") net (layer 0 also reads gamma(t)).  pts/g_pts non-null: also
+// return d(loss)/d(pts) (canonical nets with the fused encoding).
+static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
+                          const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
+                          const nrf_net_t *grads, const float *pts, float *g_pts, void *stream) {
     NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
     Planner P{};
-    const char *e = plan_net(P, net, emb, 0);
+    const char *e = plan_net(P, net, emb, time_ch);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: %s", e);
     if (n_points == 0) return NRF_OK;
+    const bool want_gx = g_pts != nullptr;
+    if (want_gx) {
+        NRF_REQUIRE(pts, "nrf_query_bwd_input: pts is null");
+        if (P.plan.xT_base < 0)
+            return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_input: input gradients need the fused encoding (embed mode 0)");
+    }
     const NetPlan &pl = P.plan;
     const int nt = pl.nt, W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
     hipStream_t st = as_stream(stream);
@@ -391,14 +433,23 @@ extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const
     const int64_t ntiles = (n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;
-    switch (nt) {
+    switch (want_gx ? -nt : nt) {
         case 8: hipLaunchKernelGGL(dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, d); break;
         case 4: hipLaunchKernelGGL(dgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, d); break;
         case 2: hipLaunchKernelGGL(dgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, d); break;
+        case -8: hipLaunchKernelGGL((dgrad_kernel<8, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        case -4: hipLaunchKernelGGL((dgrad_kernel<4, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        case -2: hipLaunchKernelGGL((dgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, d); break;
         default: return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: W = %d has no fused kernel", W);
     }
     int rc = check_launch("nrf_query_bwd (dgrad)");
     if (rc) return rc;
+    if (want_gx) {
+        hipLaunchKernelGGL(pe3_bwd_t8_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, gbuf, d.tl.g_tile,
+                           d.tl.g_xin, pts, pl.x_param, n_points, g_pts);
+        rc = check_launch("nrf_query_bwd_input (encoding backward)");
+        if (rc) return rc;
+    }
 
     Bwd B{};
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
@@ -410,10 +461,15 @@ extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const
         NRF_REQUIRE(grads->pts_w[l] && grads->pts_b[l], "nrf_query_bwd: grads->pts_w/pts_b[%d] is null", l);
         const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * W;
         bool skip = l > 0 && ((net->skips_mask >> (l - 1)) & 1);
-        int ld = l == 0 ? ic : (W + (skip ? ic : 0));
+        int ld = l == 0 ? ic + time_ch : (W + (skip ? ic : 0));
         Bwd::Dst dst{0, W, grads->pts_w[l], grads->pts_b[l]};
         if (l == 0 || skip) {  // columns fed by the position input block
             rc = B.run(gsec, W, nt, tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, ld, 0, &dst, 1);
+            if (rc) return rc;
+        }
+        if (l == 0 && time_ch) {  // columns fed by gamma(t) (vanilla_dynamic/network.py:296): 24 k-space channels
+            Bwd::Dst tdst{0, W, grads->pts_w[0], nullptr};
+            rc = B.run(gsec, W, nt, tl.a_tin, 2 * kKsT, 1, pl.t_type, pl.t_param, kKsT, 0, ld, ic, &tdst, 1);
             if (rc) return rc;
         }
         if (l > 0) {
@@ -444,4 +500,26 @@ extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const
         if (rc) return rc;
     }
     return NRF_OK;
+}
+
+extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                             const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                             void *stream) {
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, nullptr, nullptr, stream);
+}
+
+extern "C" int nrf_query_bwd_input(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                                   const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                                   const float *pts, float *g_pts, void *stream) {
+    NRF_REQUIRE(pts && g_pts, "nrf_query_bwd_input: pts / g_pts is null");
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream);
+}
+
+extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
+                                  const float *g_dx, const float *acts, float *gbuf, float *slab, int64_t n_points,
+                                  const nrf_net_t *grads, void *stream) {
+    NRF_REQUIRE(time_net && !time_net->use_viewdirs && time_net->input_ch_views > 0,
+                "nrf_dnerf_time_bwd: not a time-net descriptor");
+    return query_bwd_impl(time_net, emb, time_net->input_ch_views, packed_time, g_dx, acts, gbuf, slab, n_points, grads,
+                          nullptr, nullptr, stream);
 }

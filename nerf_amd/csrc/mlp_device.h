@@ -196,6 +196,17 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
         pl.featT_w = P.gemm_block_T(net->feature_w, W, 0, W, nt, W, nt);
         pl.viewsT_w = P.gemm_block_T(net->views_w, W + icv, 0, W, nt, W / 2, nt / 2);
     }
+    // W_x^T blocks (gradient w.r.t. the encoded position, needed when the points themselves depend on parameters:
+    // the D-NeRF chain x + dx).  Canonical nets with the fused encoding only.
+    pl.xT_base = -1; pl.xT_stride = 0;
+    if (emb->mode == 0 && time_ch == 0) {
+        pl.xT_base = P.cur;
+        pl.xT_stride = 4 * nt * 2 * 256;
+        for (int i = 0; i < D; ++i) {
+            bool skip = i > 0 && ((net->skips_mask >> (i - 1)) & 1);
+            if (i == 0 || skip) P.gemm_block_T(net->pts_w[i], i == 0 ? ic : W + ic, 0, ic, 2, W, nt);
+        }
+    }
     pl.total_floats = P.cur;
     return P.err;
 }
@@ -385,6 +396,24 @@ __device__ __forceinline__ void fill_pe3(float (&xin)[KS], float x, float y, flo
     for (int s = 6 * NPAIR; s < KS - 2; ++s) xin[s] = 0.0f;
     xin[KS - 2] = h == 0 ? x : y;
     xin[KS - 1] = h == 0 ? z : 0.0f;
+}
+
+// gamma(t) for a scalar into the static k-step slots of BLK_PE1 (see blk_chan)
+template <int KS>
+__device__ __forceinline__ void fill_pe1(float (&tin)[KS], float t, int L, int h) {
+    constexpr int NPAIR = (KS - 1) / 2;
+#pragma unroll
+    for (int j = 0; j < NPAIR; ++j) {
+        const int f = 2 * j + h;
+        const bool valid = f < L;
+        float s, c;
+        sincosf(t * (valid ? pow2i(f) : 0.0f), &s, &c);
+        tin[2 * j] = s;
+        tin[2 * j + 1] = valid ? c : 0.0f;
+    }
+#pragma unroll
+    for (int s = 2 * NPAIR; s < KS - 1; ++s) tin[s] = 0.0f;
+    tin[KS - 1] = h == 0 ? t : 0.0f;
 }
 
 template <int KS>

@@ -14,24 +14,6 @@
 
 namespace nrf {
 
-// gamma(t) for a scalar into the static k-step slots of BLK_PE1 (see blk_chan)
-template <int KS>
-__device__ __forceinline__ void fill_pe1(float (&tin)[KS], float t, int L, int h) {
-    constexpr int NPAIR = (KS - 1) / 2;
-#pragma unroll
-    for (int j = 0; j < NPAIR; ++j) {
-        const int f = 2 * j + h;
-        const bool valid = f < L;
-        float s, c;
-        sincosf(t * (valid ? pow2i(f) : 0.0f), &s, &c);
-        tin[2 * j] = s;
-        tin[2 * j + 1] = valid ? c : 0.0f;
-    }
-#pragma unroll
-    for (int s = 2 * NPAIR; s < KS - 1; ++s) tin[s] = 0.0f;
-    tin[KS - 1] = h == 0 ? t : 0.0f;
-}
-
 struct DnerfArgs {
     NetPlan tplan, cplan;         // time net (head = _time_out), canonical net
     const float *packed_t, *packed_c;

@@ -26,9 +26,11 @@ struct QueryArgs {
     int32_t pts_per_ray, x_stride, input_ch, pad_;
     float *acts;            // training mode: [n_tiles][tl.a_tile] saved inputs / activations (T8 sections)
     TrainLayout tl;
+    const float *times;     // deformation ("time") net: [P / t_div] scalar input of the second layer-0 block
+    int64_t t_div;
 };
 
-template <int NT, bool EMB, bool TRAIN>
+template <int NT, bool EMB, bool TRAIN, bool TIME = false>
 __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
     const NetPlan &pl = a.plan;
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -63,6 +65,12 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
         // trunk (network.py:48-53)
         load_bias<NT>(acc, wb, (uint32_t)pl.l0_b);
         gemm_in<kKsX, NT>(acc, xin, wb, (uint32_t)pl.l0_w);
+        if constexpr (TIME) {   // vanilla_dynamic/network.py:296: h = cat[gamma(x), gamma(t)]
+            float tin[kKsT];
+            fill_pe1<kKsT>(tin, a.times[pc / a.t_div], pl.t_param, h);
+            if constexpr (TRAIN) store_in_t8<kKsT>(tb, (uint32_t)a.tl.a_tin, tin);
+            gemm_in<kKsT, NT>(acc, tin, wb, (uint32_t)pl.l0_w2);
+        }
         relu_move<NT>(hin, acc, true);
         if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk, hin);
         for (int l = 1; l < pl.n_trunk; ++l) {
@@ -119,6 +127,12 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
     int64_t ntiles = (a.n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // 512 registers per lane -> one 4-wave workgroup per CU
+    if constexpr (!EMB) {
+        if (a.times) {
+            hipLaunchKernelGGL((query_fwd_kernel<NT, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
+            return check_launch("nrf_dnerf_time_fwd_train");
+        }
+    }
     if (a.acts)
         hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, true>), dim3(blocks), dim3(256), 0, st, a);
     else
@@ -152,16 +166,17 @@ extern "C" int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb
 
 static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
                           const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
-                          void *stream) {
+                          void *stream, const float *times = nullptr, int64_t t_div = 1) {
     NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_fwd: negative n_points");
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
                 "nrf_query_fwd: packed and raw must be 16-byte aligned");
     Planner P{};
-    const char *e = plan_net(P, net, emb, 0);
+    const char *e = plan_net(P, net, emb, times ? net->input_ch_views : 0);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: %s", e);
     if (n_points == 0) return NRF_OK;
     QueryArgs a{};
+    a.times = times; a.t_div = t_div;
     a.plan = P.plan;
     a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.raw = raw; a.n_points = n_points;
     a.input_ch = net->input_ch;
@@ -203,4 +218,16 @@ extern "C" int nrf_query_fwd_train(const nrf_net_t *net, const nrf_embed_t *emb,
                                    float *raw, float *acts, void *stream) {
     NRF_REQUIRE(acts, "nrf_query_fwd_train: acts workspace is null");
     return query_fwd_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream);
+}
+
+/* D-NeRF training: forward of the deformation ("time") net alone, saving activations -- dx = _time_out(trunk(
+ * cat[gamma(x), gamma(t)])), vanilla_dynamic/network.py:281-305.  `packed_time` from nrf_dnerf_pack_time_weights. */
+extern "C" int nrf_dnerf_time_fwd_train(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
+                                        const float *pts, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                        int32_t times_per_point, float *dx, float *acts, void *stream) {
+    NRF_REQUIRE(time_net && emb && times && acts && dx, "nrf_dnerf_time_fwd_train: null pointer");
+    NRF_REQUIRE(emb->mode == 0 && !time_net->use_viewdirs, "nrf_dnerf_time_fwd_train: needs embed mode 0 and a time-net descriptor");
+    NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0, "nrf_dnerf_time_fwd_train: n_points must be a multiple of pts_per_ray");
+    return query_fwd_impl(time_net, emb, packed_time, pts, nullptr, n_points, pts_per_ray, dx, acts, stream, times,
+                          times_per_point ? 1 : pts_per_ray);
 }

@@ -93,6 +93,8 @@ struct NetPlan {
     int64_t out_vec, out_b;             // output_linear (network.py:67) or _time_out (deformation net)
     int64_t trunkT_base, trunkT_stride; // W^T (hidden part) of trunk layer l >= 1: trunkT_base + (l-1)*stride
     int64_t featT_w, viewsT_w;          // W^T of feature_linear; of views_linears[0][:, :W]
+    int64_t xT_base, xT_stride;         // W[:, :input_ch]^T of the layers that read the position block (layer 0, skip
+                                        // layers, in layer order): input gradients for the D-NeRF chain; -1 if absent
     int64_t total_floats;
 };
 
@@ -113,6 +115,7 @@ struct TrainLayout {
     int64_t g_feat;                  // W + 32: the extra tile's row 0 is d/d(alpha)
     int64_t g_hv;                    // W/2
     int64_t g_head;                  // 32: rows 0..2 d/d(rgb)  (or d/d(output_linear out) rows 0..output_ch-1)
+    int64_t g_xin;                   // 64: d/d(gamma(x)) in the reference's channel order (only written on request)
     int64_t g_tile;
 };
 
@@ -133,6 +136,7 @@ NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
     t.g_feat = c; c += 32 * (W + 32);
     t.g_hv = c; c += 32 * (W / 2);
     t.g_head = c; c += 32 * 32;
+    t.g_xin = c; c += 32 * 64;
     t.g_tile = c;
     return t;
 }

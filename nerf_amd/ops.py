@@ -216,8 +216,9 @@ class PackedNet:
               "nrf_query_fwd_train")
         return raw, acts
 
-    def query_bwd(self, g_raw, n_points, acts):
-        """-> dict name -> gradient tensor (same shapes as the parameters)."""
+    def query_bwd(self, g_raw, n_points, acts, pts=None):
+        """-> dict name -> gradient tensor (same shapes as the parameters); with `pts` (the query points of the
+        forward) -> (that dict, d(loss)/d(pts) [P,3])."""
         g_raw = _f32(g_raw, "g_raw")
         dev = g_raw.device
         lib = _lib.lib()
@@ -236,9 +237,70 @@ class PackedNet:
             gn.rgb_w, gn.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
         else:
             gn.out_w, gn.out_b = g("output_linear.weight"), g("output_linear.bias")
-        check(lib.nrf_query_bwd(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw), _ptr(acts),
-                                _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()), "nrf_query_bwd")
+        if pts is not None:
+            pts = _f32(pts, "pts")
+            g_pts = torch.empty((n_points, 3), device=dev, dtype=torch.float32)
+            check(lib.nrf_query_bwd_input(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw),
+                                          _ptr(acts), _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _ptr(pts),
+                                          _ptr(g_pts), _stream()), "nrf_query_bwd_input")
+            return grads, g_pts
+        check(self._bwd_fn()(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw), _ptr(acts),
+                             _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()), "nrf_query_bwd")
         return grads
+
+    def _bwd_fn(self):
+        return _lib.lib().nrf_query_bwd
+
+
+class PackedTimeNet(PackedNet):
+    """The deformation ("time") net of DNeRF_Deformation (vanilla_dynamic/network.py:254-305) behind the
+    nrf_dnerf_time_* entry points.  `params` uses PackedNet's key names: pts_linears.{i}.* = the `_time` layers,
+    output_linear.* = `_time_out`; input_ch_views carries the TIME channel count."""
+
+    def __init__(self, params, D, W, input_ch, input_ch_time, skips, multires, multires_time):
+        self.params = params
+        self.net = NrfNet()
+        n = self.net
+        n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch, n.use_viewdirs = D, W, input_ch, input_ch_time, 3, 0
+        n.skips_mask = sum(1 << int(s) for s in skips)
+        self.emb = NrfEmbed(0, multires, 0, multires_time)
+        self.n_floats = _lib.lib().nrf_dnerf_time_packed_floats(C.byref(n), C.byref(self.emb))
+        if self.n_floats <= 0:
+            raise RuntimeError("nrf_dnerf_time_packed_floats: " + _lib.lib().nrf_last_error_string().decode())
+        self.packed = None
+        self._versions = None
+        self.out_ch = 3
+
+    def refresh(self):
+        vers = tuple((v.data_ptr(), v._version) for v in self.params.values())
+        if self.packed is not None and vers == self._versions:
+            return
+        self._fill_pointers()
+        dev = next(iter(self._p.values())).device
+        if self.packed is None or self.packed.device != dev:
+            self.packed = torch.empty((self.n_floats,), device=dev, dtype=torch.float32)
+        check(_lib.lib().nrf_dnerf_pack_time_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()),
+              "nrf_dnerf_pack_time_weights")
+        self._versions = vers
+
+    def query(self, *a, **k):
+        raise NotImplementedError("the time net alone is only evaluated for training; rendering uses nrf_dnerf_query_fwd")
+
+    def query_train(self, pts, times, pts_per_ray=1, times_per_point=False):
+        """-> (dx [P,3], saved workspace)."""
+        self.refresh()
+        pts, times = _f32(pts, "pts"), _f32(times, "times")
+        P = pts.shape[0]
+        dx = torch.empty((P, 3), device=pts.device, dtype=torch.float32)
+        n = _lib.lib().nrf_train_acts_floats(C.byref(self.net), P)
+        acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
+        check(_lib.lib().nrf_dnerf_time_fwd_train(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                                  _ptr(times), P, int(pts_per_ray), int(bool(times_per_point)),
+                                                  _ptr(dx), _ptr(acts), _stream()), "nrf_dnerf_time_fwd_train")
+        return dx, acts
+
+    def _bwd_fn(self):
+        return _lib.lib().nrf_dnerf_time_bwd
 
 
 class PackedNetBf16(PackedNet):

@@ -19,6 +19,53 @@ from .. import _lib, ops
 from ..network import NeRF as _StaticNeRF
 
 
+class _DeformFunction(torch.autograd.Function):
+    """(raw, dx) = deformation chain with saved activations; backward = parameter gradients of both nets
+    (autograd of vanilla_dynamic/network.py:307-341 incl. the path through embed_fn(x + dx))."""
+
+    @staticmethod
+    def forward(ctx, module, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, L, Lv, Lt, *params):
+        tnet = module._time_packed(L, Lt)
+        occ = module._occ._packed((0, L, Lv))
+        P = pts.shape[0]
+        dx, acts_t = tnet.query_train(pts, times, pts_per_ray, times_per_point)
+        # network.py:315-322: a netchunk whose FIRST point has t == 0 takes the canonical shortcut (dx = 0, no time net)
+        t_pt = times if times_per_point else times.repeat_interleave(pts_per_ray)
+        first = (torch.arange(P, device=pts.device) // netchunk) * netchunk
+        skip = (t_pt[first] == 0.0) if module.zero_canonical else torch.zeros(P, dtype=torch.bool, device=pts.device)
+        dx = torch.where(skip[:, None], torch.zeros_like(dx), dx)
+        x2 = pts + dx
+        raw, acts_c = occ.query_train(x2, viewdirs, pts_per_ray)
+        ctx.module, ctx.keys, ctx.n_points = module, (L, Lv, Lt), P
+        ctx.save_for_backward(acts_t, acts_c, x2, skip)
+        ctx.set_materialize_grads(False)
+        return raw, dx
+
+    @staticmethod
+    def backward(ctx, g_raw, g_dx_out):
+        acts_t, acts_c, x2, skip = ctx.saved_tensors
+        module, (L, Lv, Lt) = ctx.module, ctx.keys
+        occ = module._occ._packed((0, L, Lv))
+        tnet = module._time_packed(L, Lt)
+        if g_raw is None:
+            g_raw = torch.zeros((ctx.n_points, 4), device=x2.device)
+        g_occ, g_x2 = occ.query_bwd(g_raw.contiguous(), ctx.n_points, acts_c, pts=x2)
+        g_dx = g_x2 if g_dx_out is None else g_x2 + g_dx_out
+        g_dx = torch.where(skip[:, None], torch.zeros_like(g_dx), g_dx)
+        g_time = tnet.query_bwd(g_dx.contiguous(), ctx.n_points, acts_t)
+        out = []
+        for name, _ in module.named_parameters():
+            if name.startswith("_occ."):
+                out.append(g_occ.get(name[5:]))
+            elif name.startswith("_time_out."):
+                out.append(g_time.get("output_linear." + name[10:]))
+            elif name.startswith("_time."):
+                out.append(g_time.get("pts_linears." + name[6:]))
+            else:
+                out.append(None)
+        return (None,) * 10 + tuple(out)
+
+
 class NeRF(_StaticNeRF):
     """Canonical net: the static NeRF plus the (out, zeros) return convention and optional LayerNorm."""
 
@@ -123,6 +170,8 @@ class DNeRF_Deformation(nn.Module):
         self._time_versions = None
         self._packed_bf16 = None
         self._bf16_versions = None
+        self._time_net = None
+        self._time_net_key = None
         # "fp32" (the reference's arithmetic) or "bf16" (bf16 MFMA, f32 accumulate, inference only); an attribute,
         # not a constructor argument of the reference
         self.precision = "fp32"
@@ -130,6 +179,7 @@ class DNeRF_Deformation(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._packed_time = None
         self._packed_bf16 = None
+        self._time_net = None
         return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------ fused path
@@ -160,6 +210,18 @@ class DNeRF_Deformation(nn.Module):
         _lib.check(lib.nrf_dnerf_pack_time_weights(C.byref(n), C.byref(e), ops._ptr(self._packed_time), ops._stream()),
                    "nrf_dnerf_pack_time_weights")
         self._time_versions = vers
+
+    def _time_packed(self, L, Lt):
+        key = (L, Lt)
+        if self._time_net is None or self._time_net_key != key:
+            params = {}
+            for i, l in enumerate(self._time):
+                params[f"pts_linears.{i}.weight"], params[f"pts_linears.{i}.bias"] = l.weight, l.bias
+            params["output_linear.weight"], params["output_linear.bias"] = self._time_out.weight, self._time_out.bias
+            self._time_net = ops.PackedTimeNet(params, self.D_deform, self.W_deform, self.input_ch, self.input_ch_time,
+                                               list(self.skips_deform), L, Lt)
+            self._time_net_key = key
+        return self._time_net
 
     def _time_params(self):
         return [p for l in self._time for p in (l.weight, l.bias)] + [self._time_out.weight, self._time_out.bias]
@@ -204,13 +266,17 @@ class DNeRF_Deformation(nn.Module):
                      multires_time):
         """Fused deformation chain on raw inputs: pts [P,3], viewdirs [P/pts_per_ray,3], times [P] or
         [P/pts_per_ray] -> (raw [P,4], dx [P,3])."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("nerf_amd: training through the D-NeRF deformation chain is not built yet "
-                                      "(run under torch.no_grad() to render)")
         if self.use_layernorm or not self.use_viewdirs:
             raise RuntimeError("nerf_amd: the fused deformation kernel needs use_viewdirs=True, use_layernorm=False")
         pts, viewdirs = ops._f32(pts, "pts"), ops._f32(viewdirs, "viewdirs")
         times = ops._f32(times, "times").reshape(-1)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: exact f32 kernels with saved activations (whatever `precision` says)
+            if pts.requires_grad or times.requires_grad:
+                raise NotImplementedError("nerf_amd: gradients w.r.t. points / times are not built (parameters only)")
+            return _DeformFunction.apply(self, pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
+                                         int(netchunk), multires, multires_views, multires_time,
+                                         *[p for _, p in self.named_parameters()])
         if self.precision == "bf16":
             return self._query_points_bf16(pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires,
                                            multires_views, multires_time)
