@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short secondary measurements (N=1 only)")
     ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -140,6 +141,46 @@ def hbm_kernels(torch, device, n_rays=32768, reps=20):
         out[name] = {"us_per_launch": round(us, 2), "bytes_per_ray": bytes_per_ray, "GB/s": round(gbs, 1),
                      "frac_of_8TB/s": round(gbs / 8000.0, 4)}
     return out
+
+
+def extras(args, torch, dist, device, coarse, fine, step, timer):
+    """Short secondary measurements on the same GPU, reported beside the headline (never instead of it): the bf16
+    variant of the same render, the 4096-ray training step, and the D-NeRF deformation render in fp32 and bf16."""
+    import copy
+    import bench_dnerf
+    import bench_train
+    also = {}
+
+    def brief(o):
+        return {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "dtype": o["dtype"],
+                "roofline_frac": o["roofline"]["frac"], "achieved_TFLOPs": o["roofline"]["achieved"],
+                "workload": o["config"]["workload"]}
+    # the same 800x800 render with bf16 MFMA
+    coarse.precision = fine.precision = "bf16"
+    step(0)
+    torch.cuda.synchronize()
+    timer.events.clear()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(3):
+        step(i + 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    timer.enabled = False
+    q_ms, q_pts, q_n = timer.summary()
+    tf = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12
+    also["render_bf16"] = {"value": args.size * args.size / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "bf16",
+                           "roofline_frac": tf / PEAK_BF16_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+                           "workload": f"the same {args.size}x{args.size} render, bf16 MFMA variant (tolerance 1e-2)"}
+    coarse.precision = fine.precision = "fp32"
+    a = copy.copy(args)
+    a.steps, a.warmup = 10, 3
+    also["train_step"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
+    a.steps, a.warmup = 2, 1
+    for prec in ("fp32", "bf16"):
+        a.precision = prec
+        also[f"dnerf_{prec}"] = brief(bench_dnerf.run_dnerf(a, torch, dist, 1, 0, device, emit=False))
+    return also
 
 
 def cpu_baseline(n_rays):
@@ -281,6 +322,8 @@ def main():
                          "query_share_of_step": q_ms * 1e-3 / dt},
         }
         out["hbm_kernels"] = hbm_kernels(torch, device)
+        if world == 1 and not args.no_extras and args.workload == "render" and not bf16:
+            out["also"] = extras(args, torch, dist, device, coarse, fine, step, timer)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays)
         print(json.dumps(out), flush=True)

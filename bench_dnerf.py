@@ -12,7 +12,7 @@ OCC_MAC = 63 * 256 + 6 * 256 * 256 + 319 * 256 + 256 * 256 + 256 + 283 * 128 + 1
 FLOP_PER_POINT = 2 * (TIME_MAC + OCC_MAC)
 
 
-def run_dnerf(args, torch, dist, world, rank, device):
+def run_dnerf(args, torch, dist, world, rank, device, emit=True):
     import nerf_fixtures as fx
     import nerf_amd.vanilla_dynamic as vd
     from bench import PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS
@@ -84,6 +84,7 @@ def run_dnerf(args, torch, dist, world, rank, device):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    out = None
     if rank == 0:
         q_ms = sum(a.elapsed_time(b) for a, b, _ in events)
         q_pts = sum(n for _, _, n in events)
@@ -104,7 +105,9 @@ def run_dnerf(args, torch, dist, world, rank, device):
                          "launches": len(events), "avg_launch_ms": q_ms / max(len(events), 1),
                          "flop_per_point": FLOP_PER_POINT, "query_share_of_step": q_ms * 1e-3 / dt},
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        if emit:
+            print(json.dumps(out), flush=True)
+    if world > 1 and emit:
         dist.barrier()
         dist.destroy_process_group()
+    return out if rank == 0 else None

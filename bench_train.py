@@ -27,7 +27,7 @@ def step_traffic():
         return None
 
 
-def run_train(args, torch, dist, world, rank, device):
+def run_train(args, torch, dist, world, rank, device, emit=True):
     import nerf_fixtures as fx
     from bench import PEAK_F32_MFMA_TFLOPS, build_nets
     from nerf_amd import parallel
@@ -79,6 +79,7 @@ def run_train(args, torch, dist, world, rank, device):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    out = None
     if rank == 0:
         pts = n_global * 256
         achieved = pts * STEP_FLOP_PER_POINT * args.steps / dt / 1e12
@@ -96,7 +97,9 @@ def run_train(args, torch, dist, world, rank, device):
                          "kernel": "whole step (query_fwd<train> + dgrad + wgrad kernels); algorithmic "
                                    "3.489 MFLOP/point over wall time; traffic = HBM bytes per STEP over all kernels"},
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        if emit:
+            print(json.dumps(out), flush=True)
+    if world > 1 and emit:
         dist.barrier()
         dist.destroy_process_group()
+    return out if rank == 0 else None
