@@ -218,29 +218,41 @@ __global__ void __launch_bounds__(256) pe3_bwd_t8_kernel(const float *gbuf, int6
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: slab[chunk][n][k] = sum_{points in chunk} G[n][p] * X[k][p]
+//
+// A workgroup owns a super-block of up to 8 x 8 channel tiles (256 x 256 of dW); wave (wy, wx) accumulates its
+// 4 x 4 tiles (256 accumulator registers).  Per step (8 points of one 32-point tile) the operands are the
+// super-block's <= 8 G pieces and <= 8 X pieces of 1 KiB; the four waves copy them global -> LDS ONCE
+// (buffer_load ... lds, a 3-stage ring, one barrier per step) and every wave reads its 4 + 4 fragments from LDS.
+// Without the sharing each wave pulled its own 8 KiB per 64 MFMAs = 8 B/clk/CU, the per-CU load limit (measured 60 %
+// of peak); shared it is 4 B/clk/CU.  X may be the concatenation of two T8 sections (cat[h, gamma(x)] of a skip
+// layer, cat[feature, gamma(d)] of the view layer), so one launch covers a whole nn.Linear.
 struct WgradArgs {
     const float *gbuf;   // tile stride g_tile
     const float *acts;   // tile stride a_tile
     float *slab;         // [nchunks][NP*KP] partial dW, then [nchunks][NP] partial db
-    int64_t g_tile, a_tile, g_sec, a_sec;
+    int64_t g_tile, a_tile, g_sec;
+    int64_t a_sec[2];        // X = section 0 (k_tiles0 tiles) followed by section 1
     int64_t ntiles;
-    int32_t Cg, Ca;          // channels in the two T8 sections
-    int32_t n_tiles, k_tiles;  // 32-channel tiles of G (rows of dW) and of X (columns)
+    int32_t Cg, Ca[2];       // channels in the T8 sections
+    int32_t n_tiles, k_tiles, k_tiles0;  // 32-channel tiles of G (rows of dW) and of X (columns)
     int32_t chunk_tiles, nchunks;
 };
 
+constexpr int kWgStage = 16384;
+
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int chunk = blockIdx.x;
-    const int k_blks = (a.k_tiles + 3) >> 2, n_blks = (a.n_tiles + 3) >> 2;
-    const int job = blockIdx.y * 4 + wib;
-    if (job >= k_blks * n_blks) return;
-    const int nb = job / k_blks, kb = job - nb * k_blks;
-    const int n0 = nb * 4, k0 = kb * 4;
-    const int na = min(4, a.n_tiles - n0), ka = min(4, a.k_tiles - k0);
+    const int k_sblks = (a.k_tiles + 7) >> 3;
+    const int nsb = blockIdx.y / k_sblks, ksb = blockIdx.y - nsb * k_sblks;
+    const int gn = min(8, a.n_tiles - nsb * 8), xn = min(8, a.k_tiles - ksb * 8);   // pieces of the super-block
+    const int n0 = nsb * 8 + (wib >> 1) * 4, k0 = ksb * 8 + (wib & 1) * 4;
+    const int na = max(0, min(4, a.n_tiles - n0)), ka = max(0, min(4, a.k_tiles - k0));
+    const bool active = na > 0 && ka > 0;
     const int NP = a.n_tiles * 32, KP = a.k_tiles * 32;
-    const int lane_off = ((lane & 31) * 8 + (lane >> 5) * 4) * 4;  // bytes: channel c = lane&31, points 4s..4s+3
+    const int lane_src = ((lane & 31) * 8 + (lane >> 5) * 4) * 4;  // bytes in a piece: channel lane&31, points 4s..4s+3
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -253,48 +265,74 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
 
     const int64_t t0 = (int64_t)chunk * a.chunk_tiles;
     const int64_t t1 = min(a.ntiles, t0 + a.chunk_tiles);
-    // one step = 8 points (m) of one tile: up to 8 wave loads (1 KiB each) feeding up to 64 MFMAs.
-    // Software pipeline: step i+1's loads are issued before step i's MFMAs (4096 cycles of cover).
-    const int64_t nsteps = (t1 - t0) * 4;
-    f32x4 A[4], B[4], An[4], Bn[4];
-    auto load_step = [&](int64_t step, f32x4(&Ax)[4], f32x4(&Bx)[4]) {
+    const int64_t nsteps = (t1 - t0) * 4;   // one step = 8 points (m) of one tile
+
+    // copy this wave's share of step `step`'s pieces into `stage`: piece i (G pieces first, then X) by wave i & 3
+    auto request = [&](int64_t step, int stage) {
         const int64_t tile = t0 + (step >> 2);
         const int m = (int)(step & 3);
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.gbuf) + tile * a.g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(a.acts) + tile * a.a_tile + a.a_sec, 0, a.Ca * 32 * 4, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = wib + 4 * q;
+            char *dst = lds + stage * kWgStage + i * 1024;
+            if (i < gn) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)dst, 16, lane_src,
+                                                         ((m * a.Cg + 32 * (nsb * 8 + i)) * 8) * 4, 0, 0);
+            } else if (i - 8 < xn && i >= 8) {
+                const int kt = ksb * 8 + (i - 8);
+                const int sec = kt >= a.k_tiles0;
+                const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
+                __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(a.acts) + tile * a.a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 4, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)dst, 16, lane_src,
+                                                         ((m * a.Ca[sec] + c0) * 8) * 4, 0, 0);
+            }
+        }
+    };
+    f32x4 A[4], B[4];
+    auto read_frags = [&](int stage) {
+        const char *base = lds + stage * kWgStage + lane * 16;
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-            if (x < na)
-                Ax[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rg, lane_off, ((m * a.Cg + 32 * (n0 + x)) * 8) * 4, 0));
+            if (x < na) A[x] = *reinterpret_cast<const f32x4 *>(base + ((wib >> 1) * 4 + x) * 1024);
 #pragma unroll
         for (int y = 0; y < 4; ++y)
-            if (y < ka)
-                Bx[y] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rx, lane_off, ((m * a.Ca + 32 * (k0 + y)) * 8) * 4, 0));
+            if (y < ka) B[y] = *reinterpret_cast<const f32x4 *>(base + (8 + (wib & 1) * 4 + y) * 1024);
     };
-    if (nsteps > 0) load_step(0, A, B);
+
+    if (nsteps > 0) request(0, 0);
+    if (nsteps > 1) request(1, 1);
+    int st_cur = 0, st_req = 2;
     for (int64_t step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) load_step(step + 1, An, Bn);
-        __builtin_amdgcn_sched_barrier(0);
+        // own copies of step+1 (and older) have landed; after the barrier everyone's have, and everyone has finished
+        // reading step-1's stage, which the request for step+2 reuses
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) request(step + 2, st_req);
+        if (active) {
+            read_frags(st_cur);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (x < na) {
-                bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
+            for (int x = 0; x < 4; ++x)
+                if (x < na) {
+                    bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
 #pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    if (y < ka) {
+                    for (int y = 0; y < 4; ++y)
+                        if (y < ka) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
-                    }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { A[x] = An[x]; B[x] = Bn[x]; }
+                            for (int j = 0; j < 4; ++j)
+                                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
+                        }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st_cur = st_cur == 2 ? 0 : st_cur + 1;
+        st_req = st_req == 2 ? 0 : st_req + 1;
     }
+    if (!active) return;
     float *slab = a.slab + (int64_t)chunk * NP * KP;
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -308,7 +346,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
                         slab[(int64_t)row * KP + 32 * (k0 + y) + (lane & 31)] = acc[x][y][r];
                     }
                 }
-            if (kb == 0) {
+            if (k0 == 0) {
                 float v = bs[x] + __shfl_xor(bs[x], 32);
                 if (lane < 32) a.slab[(int64_t)a.nchunks * NP * KP + (int64_t)chunk * NP + 32 * (n0 + x) + lane] = v;
             }
@@ -321,18 +359,19 @@ struct ReduceArgs {
     float *dst_w;   // [n_valid, ld]
     float *dst_b;   // [n_valid] or null
     int32_t nchunks, NP, KP, row0, n_valid, ld, ch_off;
-    int32_t x_type, x_param, x_ks;  // how slab column k maps to an input channel (BLK_HIDDEN: identity)
+    int32_t x_type, x_param, x_ks;  // how slab column kc + k maps to an input channel (BLK_HIDDEN: identity)
     int32_t k_valid;                // columns holding live channels (BLK_HIDDEN)
+    int32_t kc, kn;                 // the slab columns [kc, kc + kn) this launch unpacks
 };
 
 __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceArgs a) {
-    const int total = a.n_valid * a.KP;
+    const int total = a.n_valid * a.kn;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + a.n_valid; e += gridDim.x * blockDim.x) {
         if (e < total) {
-            int n = e / a.KP, k = e - n * a.KP;
+            int n = e / a.kn, k = e - n * a.kn;
             int chan = (a.x_type == BLK_HIDDEN) ? (k < a.k_valid ? k : -1) : blk_chan(a.x_type, a.x_param, a.x_ks, k & 1, k >> 1);
             if (chan < 0) continue;
-            const float *s = a.slab + (int64_t)(a.row0 + n) * a.KP + k;
+            const float *s = a.slab + (int64_t)(a.row0 + n) * a.KP + a.kc + k;
             float v = 0.0f;
             for (int c = 0; c < a.nchunks; ++c) v += s[(int64_t)c * a.NP * a.KP];
             a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = v;
@@ -358,25 +397,34 @@ struct Bwd {
     int nchunks, chunk_tiles;
     hipStream_t st;
 
-    // one wgrad GEMM + its reductions.  dsts: up to two (row0, n_valid, dst_w, dst_b) destinations
+    // One wgrad GEMM (a whole nn.Linear: G x cat[X parts]) + its reductions.
     struct Dst { int row0, n_valid; const float *w; const float *b; };
-    int run(int64_t g_sec, int Cg, int n_tiles, int64_t a_sec, int Ca, int k_tiles, int x_type, int x_param, int x_ks,
-            int k_valid, int ld, int ch_off, const Dst *dsts, int ndst) {
+    struct XPart { int64_t sec; int C, tiles, type, param, ks, k_valid, ch_off; };   // a T8 section and how its columns unpack
+    int run(int64_t g_sec, int Cg, int n_tiles, const XPart *xp, int nparts, int ld, const Dst *dsts, int ndst) {
         WgradArgs w{};
         w.gbuf = gbuf; w.acts = acts; w.slab = slab;
-        w.g_tile = tl.g_tile; w.a_tile = tl.a_tile; w.g_sec = g_sec; w.a_sec = a_sec;
-        w.ntiles = ntiles; w.Cg = Cg; w.Ca = Ca; w.n_tiles = n_tiles; w.k_tiles = k_tiles;
+        w.g_tile = tl.g_tile; w.a_tile = tl.a_tile; w.g_sec = g_sec;
+        w.ntiles = ntiles; w.Cg = Cg; w.n_tiles = n_tiles;
+        w.a_sec[0] = xp[0].sec; w.Ca[0] = xp[0].C; w.k_tiles0 = xp[0].tiles; w.k_tiles = xp[0].tiles;
+        w.a_sec[1] = xp[0].sec; w.Ca[1] = xp[0].C;
+        if (nparts > 1) { w.a_sec[1] = xp[1].sec; w.Ca[1] = xp[1].C; w.k_tiles += xp[1].tiles; }
         w.chunk_tiles = chunk_tiles; w.nchunks = nchunks;
-        int jobs = ((n_tiles + 3) / 4) * ((k_tiles + 3) / 4);
-        hipLaunchKernelGGL(wgrad_kernel, dim3(nchunks, (jobs + 3) / 4), dim3(256), 0, st, w);
+        const int sblks = ((n_tiles + 7) / 8) * ((w.k_tiles + 7) / 8);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(nchunks, sblks), dim3(256), 0, st, w);
         for (int i = 0; i < ndst; ++i) {
-            ReduceArgs r{};
-            r.slab = slab; r.dst_w = const_cast<float *>(dsts[i].w); r.dst_b = const_cast<float *>(dsts[i].b);
-            r.nchunks = nchunks; r.NP = n_tiles * 32; r.KP = k_tiles * 32; r.row0 = dsts[i].row0;
-            r.n_valid = dsts[i].n_valid; r.ld = ld; r.ch_off = ch_off;
-            r.x_type = x_type; r.x_param = x_param; r.x_ks = x_ks; r.k_valid = k_valid;
-            int total = r.n_valid * (r.KP + 1);
-            hipLaunchKernelGGL(reduce_unpack_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, r);
+            int kc = 0;
+            for (int q = 0; q < nparts; ++q) {
+                ReduceArgs r{};
+                r.slab = slab; r.dst_w = const_cast<float *>(dsts[i].w);
+                r.dst_b = q == 0 ? const_cast<float *>(dsts[i].b) : nullptr;
+                r.nchunks = nchunks; r.NP = n_tiles * 32; r.KP = w.k_tiles * 32; r.row0 = dsts[i].row0;
+                r.n_valid = dsts[i].n_valid; r.ld = ld; r.ch_off = xp[q].ch_off;
+                r.x_type = xp[q].type; r.x_param = xp[q].param; r.x_ks = xp[q].ks; r.k_valid = xp[q].k_valid;
+                r.kc = kc; r.kn = xp[q].tiles * 32;
+                kc += r.kn;
+                int total = r.n_valid * (r.kn + 1);
+                hipLaunchKernelGGL(reduce_unpack_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, r);
+            }
         }
         return check_launch("nrf_query_bwd (wgrad)");
     }
@@ -402,8 +450,7 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
     if (!net || net->W % 32 || n_points < 0) return -1;
     int ct;
     int64_t nchunks = pick_chunks((n_points + 31) / 32, &ct);
-    int64_t np = net->W + 32, kp = net->W;  // the largest GEMM: (feature + alpha row) x hidden
-    if (kp < 64) kp = 64;
+    int64_t np = net->W + 32, kp = net->W + 2 * kKsX;  // bound on every GEMM: (feature + alpha row) x cat[hidden, gamma(x)]
     return nchunks * (np * kp + np);
 }
 
@@ -457,46 +504,47 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles);
     const TrainLayout &tl = d.tl;
     const int xk = 2 * kKsX / 32, dk = 2 * kKsD / 32;  // 32-channel tiles of the k-space input blocks
+    const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};
     for (int l = 0; l < D; ++l) {
         NRF_REQUIRE(grads->pts_w[l] && grads->pts_b[l], "nrf_query_bwd: grads->pts_w/pts_b[%d] is null", l);
         const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * W;
         bool skip = l > 0 && ((net->skips_mask >> (l - 1)) & 1);
         int ld = l == 0 ? ic + time_ch : (W + (skip ? ic : 0));
         Bwd::Dst dst{0, W, grads->pts_w[l], grads->pts_b[l]};
-        if (l == 0 || skip) {  // columns fed by the position input block
-            rc = B.run(gsec, W, nt, tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, ld, 0, &dst, 1);
-            if (rc) return rc;
+        Bwd::XPart parts[2];
+        int np = 0;
+        if (l == 0) {
+            parts[np++] = Xin;
+            if (time_ch)   // columns fed by gamma(t) (vanilla_dynamic/network.py:296): 24 k-space channels
+                parts[np++] = Bwd::XPart{tl.a_tin, 2 * kKsT, 1, pl.t_type, pl.t_param, kKsT, 0, ic};
+        } else {
+            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * 32 * W, W, nt, BLK_HIDDEN, 0, 0, W, skip ? ic : 0};
+            if (skip) parts[np++] = Xin;   // network.py:52-53: cat[input_pts, h]
         }
-        if (l == 0 && time_ch) {  // columns fed by gamma(t) (vanilla_dynamic/network.py:296): 24 k-space channels
-            Bwd::Dst tdst{0, W, grads->pts_w[0], nullptr};
-            rc = B.run(gsec, W, nt, tl.a_tin, 2 * kKsT, 1, pl.t_type, pl.t_param, kKsT, 0, ld, ic, &tdst, 1);
-            if (rc) return rc;
-        }
-        if (l > 0) {
-            rc = B.run(gsec, W, nt, tl.a_trunk + (int64_t)(l - 1) * 32 * W, W, nt, BLK_HIDDEN, 0, 0, W, ld,
-                       skip ? ic : 0, &dst, 1);
-            if (rc) return rc;
-        }
+        rc = B.run(gsec, W, nt, parts, np, ld, &dst, 1);
+        if (rc) return rc;
     }
     const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * 32 * W;
+    const Bwd::XPart Hlast{a_last, W, nt, BLK_HIDDEN, 0, 0, W, 0};
     if (pl.use_viewdirs) {
         NRF_REQUIRE(grads->feature_w && grads->feature_b && grads->alpha_w && grads->alpha_b && grads->views_w &&
                     grads->views_b && grads->rgb_w && grads->rgb_b, "nrf_query_bwd: a head gradient pointer is null");
         Bwd::Dst fd[2] = {{0, W, grads->feature_w, grads->feature_b}, {W, 1, grads->alpha_w, grads->alpha_b}};
-        rc = B.run(tl.g_feat, W + 32, nt + 1, a_last, W, nt, BLK_HIDDEN, 0, 0, W, W, 0, fd, 2);
+        rc = B.run(tl.g_feat, W + 32, nt + 1, &Hlast, 1, W, fd, 2);
         if (rc) return rc;
         Bwd::Dst vd{0, W / 2, grads->views_w, grads->views_b};
-        rc = B.run(tl.g_hv, W / 2, nt / 2, tl.a_feat, W, nt, BLK_HIDDEN, 0, 0, W, W + icv, 0, &vd, 1);
-        if (rc) return rc;
-        rc = B.run(tl.g_hv, W / 2, nt / 2, tl.a_din, 2 * kKsD, dk, pl.d_type, pl.d_param, kKsD, 0, W + icv, W, &vd, 1);
+        Bwd::XPart vparts[2] = {{tl.a_feat, W, nt, BLK_HIDDEN, 0, 0, W, 0},
+                                {tl.a_din, 2 * kKsD, dk, pl.d_type, pl.d_param, kKsD, 0, W}};   // network.py:58: cat[feature, views]
+        rc = B.run(tl.g_hv, W / 2, nt / 2, vparts, 2, W + icv, &vd, 1);
         if (rc) return rc;
         Bwd::Dst rd{0, 3, grads->rgb_w, grads->rgb_b};
-        rc = B.run(tl.g_head, 32, 1, tl.a_hv, W / 2, nt / 2, BLK_HIDDEN, 0, 0, W / 2, W / 2, 0, &rd, 1);
+        Bwd::XPart hv{tl.a_hv, W / 2, nt / 2, BLK_HIDDEN, 0, 0, W / 2, 0};
+        rc = B.run(tl.g_head, 32, 1, &hv, 1, W / 2, &rd, 1);
         if (rc) return rc;
     } else {
         NRF_REQUIRE(grads->out_w && grads->out_b, "nrf_query_bwd: grads->out_w/out_b is null");
         Bwd::Dst od{0, pl.output_ch, grads->out_w, grads->out_b};
-        rc = B.run(tl.g_head, 32, 1, a_last, W, nt, BLK_HIDDEN, 0, 0, W, W, 0, &od, 1);
+        rc = B.run(tl.g_head, 32, 1, &Hlast, 1, W, &od, 1);
         if (rc) return rc;
     }
     return NRF_OK;
