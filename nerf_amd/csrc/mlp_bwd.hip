@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
                 axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 0 * (NT / 2) * 32, gr.x);
                 axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NT / 2) * 32, gr.y);
                 axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NT / 2) * 32, gr.z);
-                relu_mask_t8<NT / 2>(ta, (uint32_t)tl.a_hv, g2);
+                apply_gate_bits<NT / 2>(load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane), g2);
                 store_acc_t8c<NT / 2>(tg, (uint32_t)tl.g_hv, W / 2, g2);
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
                 gemm_hid<NT / 2, NT>(g, g2, wb, (uint32_t)pl.viewsT_w);
@@ -173,8 +173,10 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
                 if (o < pl.output_ch) axpy_head<NT>(g, wb, (uint32_t)pl.out_vec + o * NT * 32, ho[o]);
         }
         // trunk in reverse (network.py:49-53)
+        u32x4 gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (pl.n_trunk - 1) * 256, lane);
         for (int l = pl.n_trunk - 1; l >= 0; --l) {
-            relu_mask_t8<NT>(ta, (uint32_t)tl.a_trunk + l * (32 * W), g);
+            apply_gate_bits<NT>(gate, g);
+            if (l > 0) gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);   // in flight during this layer's GEMM
             store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk + l * (32 * W), W, g);
             if constexpr (GX) {
                 if (l == 0 || ((pl.skip_in_mask >> l) & 1)) {   // g_x += W_l[:, :input_ch]^T g_l

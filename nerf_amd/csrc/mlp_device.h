@@ -351,6 +351,34 @@ __device__ __forceinline__ void store_acc_t8(const TBuf &tb, uint32_t sec, const
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ReLU gates of NT tiles as bits (the backward chain's only use of the trunk activations): tile t, register r ->
+// dword t>>1, bit 31 - (16(t&1) + r).  h = max(z, 0) >= 0, so min(bits, 1) is 1 exactly where h > 0.
+template <int NT>
+__device__ __forceinline__ void store_gate_bits(const TBuf &tb, uint32_t slot, const f32x16 (&h)[NT], int lane) {
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t b = min(__float_as_uint(h[t][r]), 1u);
+            m[t >> 1] = (m[t >> 1] << 1) | b;
+        }
+    if constexpr (NT & 1) m[NT >> 1] <<= 16;
+    u32x4 v = {m[0], m[1], m[2], m[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(v, tb.rsrc, lane * 16, (int)(slot * 4), 0);
+}
+__device__ __forceinline__ u32x4 load_gate_bits(const TBuf &tb, uint32_t slot, int lane) {
+    return __builtin_amdgcn_raw_buffer_load_b128(tb.rsrc, lane * 16, (int)(slot * 4), 0);
+}
+template <int NT>
+__device__ __forceinline__ void apply_gate_bits(const u32x4 &m, f32x16 (&g)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            g[t][r] = (int32_t)(m[t >> 1] << (16 * (t & 1) + r)) < 0 ? g[t][r] : 0.0f;
+}
+
 template <int NT>
 __device__ __forceinline__ void load_acc_t8(const TBuf &tb, uint32_t sec, f32x16 (&v)[NT]) {
     constexpr int C = 32 * NT;

@@ -72,14 +72,20 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             gemm_in<kKsT, NT>(acc, tin, wb, (uint32_t)pl.l0_w2);
         }
         relu_move<NT>(hin, acc, true);
-        if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk, hin);
+        if constexpr (TRAIN) {
+            store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk, hin);
+            store_gate_bits<NT>(tb, (uint32_t)a.tl.a_mask, hin, lane);
+        }
         for (int l = 1; l < pl.n_trunk; ++l) {
             const uint32_t slot = (uint32_t)(pl.trunk_base + (int64_t)(l - 1) * pl.trunk_stride);
             load_bias<NT>(acc, wb, slot);
             if ((pl.skip_in_mask >> l) & 1) gemm_in<kKsX, NT>(acc, xin, wb, slot + skip_off);
             gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
             relu_move<NT>(hin, acc, true);
-            if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk + l * (32 * 32 * NT), hin);
+            if constexpr (TRAIN) {
+                store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk + l * (32 * 32 * NT), hin);
+                store_gate_bits<NT>(tb, (uint32_t)a.tl.a_mask + l * 256, hin, lane);
+            }
         }
         if (pl.use_viewdirs) {
             if constexpr (NT >= 2) {
@@ -103,7 +109,10 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 if constexpr (TRAIN) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
                 gemm_in<kKsD, NT / 2>(acc2, din, wb, (uint32_t)pl.views_w_in);
                 relu_move<NT / 2>(acc2, acc2, true);
-                if constexpr (TRAIN) store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);
+                if constexpr (TRAIN) {
+                    store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);
+                    store_gate_bits<NT / 2>(tb, (uint32_t)a.tl.a_mask + pl.n_trunk * 256, acc2, lane);
+                }
                 const uint32_t rv = (uint32_t)pl.rgb_vec, rb = (uint32_t)pl.rgb_b * 4;
                 float4 o;                                                                        // network.py:64-65
                 o.x = head_dot<NT / 2>(acc2, wb, rv + 0 * (NT / 2) * 32) + wload1(wb, rb + 0);

@@ -109,6 +109,7 @@ struct TrainLayout {
     int64_t a_xin, a_din, a_tin;     // input blocks in k-step space: channel 2*step + half (64 / 32 / 24 ch)
     int64_t a_trunk;                 // D sections of W channels: post-ReLU outputs of trunk layer l
     int64_t a_feat, a_hv;            // feature_linear output (W), views layer output (W/2, post-ReLU)
+    int64_t a_mask;                  // ReLU gates as bits: D + 1 slots (trunk layers, view layer) of [64 lanes][4 dwords]
     int64_t a_tile;                  // floats per tile
     // gradients w.r.t. pre-activations
     int64_t g_trunk;                 // D sections of W
@@ -130,6 +131,7 @@ NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
     t.a_trunk = c; c += (int64_t)32 * W * D;
     t.a_feat = c; c += 32 * W;
     t.a_hv = c; c += 32 * (W / 2);
+    t.a_mask = c; c += (int64_t)256 * (D + 1);
     t.a_tile = c;
     c = 0;
     t.g_trunk = c; c += (int64_t)32 * W * D;

@@ -45,7 +45,7 @@ def test_version_and_size_queries():
     assert floats > 595844 and floats < 3 * 595844
     pts = 4096 * 192
     per_pt = l.nrf_train_acts_floats(C.byref(n), pts) / pts
-    assert per_pt == 64 + 32 + 24 + 8 * 256 + 256 + 128      # k-space inputs + trunk + feature + view layer
+    assert per_pt == 64 + 32 + 24 + 8 * 256 + 256 + 128 + 8 * 9      # k-space inputs + trunk + feature + view layer
     assert l.nrf_train_grads_floats(C.byref(n), pts) / pts == 8 * 256 + 288 + 128 + 32 + 64
     assert l.nrf_train_slab_floats(C.byref(n), pts) == 256 * (288 * 320 + 288)
     # ragged point counts round up to whole 32-point tiles

@@ -256,7 +256,7 @@ def _grad_check(ops, sd, pts, dirs, S, g_out, **kw):
         e = np.concatenate([e, orc.embed(np.repeat(dirs, S, axis=0), 4)], -1)
     # saved activations: decode the T8 workspace ([4][C][8] per 32-point tile) and check it against the oracle
     D, W, P = cfg["D"], cfg["W"], pts.shape[0]
-    a = host(acts).reshape(-1, 32 * (64 + 32 + 24 + D * W + W + W // 2))
+    a = host(acts).reshape(-1, 32 * (64 + 32 + 24 + D * W + W + W // 2) + 256 * (D + 1))   # + ReLU gate bits
 
     def section(off, C):
         t = a[:, off:off + 32 * C].reshape(-1, 4, C, 8)                 # tile, m, channel, q7
