@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--size", type=int, default=800, help="image side (render workload)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
+    ap.add_argument("--train-rays", type=int, default=4096, help="global ray batch of the train workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short secondary measurements (N=1 only)")
     ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")

@@ -43,7 +43,7 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
     kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=1., N_importance=128,
               network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
               raw_noise_std=0., ndc=False, lindisp=False)
-    n_global = 4096
+    n_global = getattr(args, "train_rays", 4096)
     ro, rd, target = fx.train_batch(n_global, seed=1)
     r0, n_local = parallel.slice_partition(n_global, world)[rank]
     batch_rays = torch.stack([torch.from_numpy(ro[r0:r0 + n_local]), torch.from_numpy(rd[r0:r0 + n_local])]).to(device)
@@ -89,7 +89,7 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "lego-shaped training step, 4096-ray batch, 64+128 samples, D=8 W=256 coarse+fine, "
+            "config": {"workload": f"lego-shaped training step, {n_global}-ray batch, 64+128 samples, D=8 W=256 coarse+fine, "
                                    "fp32, forward+backward+Adam", "global_batch_rays": n_global,
                        "parallelism": f"dp{world}, one flat all-reduce (4.77 MB)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

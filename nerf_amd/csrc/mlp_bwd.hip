@@ -374,9 +374,19 @@ __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceArgs a) 
             int chan = (a.x_type == BLK_HIDDEN) ? (k < a.k_valid ? k : -1) : blk_chan(a.x_type, a.x_param, a.x_ks, k & 1, k >> 1);
             if (chan < 0) continue;
             const float *s = a.slab + (int64_t)(a.row0 + n) * a.KP + a.kc + k;
-            float v = 0.0f;
-            for (int c = 0; c < a.nchunks; ++c) v += s[(int64_t)c * a.NP * a.KP];
-            a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = v;
+            const int64_t stride = (int64_t)a.NP * a.KP;
+            // fixed summation order (deterministic): four interleaved partial sums, 8 loads in flight
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+            int c = 0;
+            for (; c + 8 <= a.nchunks; c += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = s[(c + u) * stride];
+                v0 += t[0]; v1 += t[1]; v2 += t[2]; v3 += t[3];
+                v0 += t[4]; v1 += t[5]; v2 += t[6]; v3 += t[7];
+            }
+            for (; c < a.nchunks; ++c) v0 += s[c * stride];
+            a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = (v0 + v1) + (v2 + v3);
         } else if (a.dst_b) {
             int n = e - total;
             const float *s = a.slab + (int64_t)a.nchunks * a.NP * a.KP + a.row0 + n;
