@@ -366,33 +366,55 @@ struct ReduceArgs {
     int32_t kc, kn;                 // the slab columns [kc, kc + kn) this launch unpacks
 };
 
+// Bandwidth-bound (nchunks x dW bytes): 4 lanes share one output quad, each summing a quarter of the chunks with
+// 8 float4 loads in flight, combined by shuffles in a FIXED order (bit-reproducible gradients).
 __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceArgs a) {
-    const int total = a.n_valid * a.kn;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + a.n_valid; e += gridDim.x * blockDim.x) {
-        if (e < total) {
-            int n = e / a.kn, k = e - n * a.kn;
-            int chan = (a.x_type == BLK_HIDDEN) ? (k < a.k_valid ? k : -1) : blk_chan(a.x_type, a.x_param, a.x_ks, k & 1, k >> 1);
-            if (chan < 0) continue;
+    const int kq = a.kn >> 2;                       // quads per row (kn is a multiple of 32)
+    const int total_q = a.n_valid * kq;
+    const int sub = threadIdx.x & 3;
+    const int64_t stride = (int64_t)a.NP * a.KP;
+    const int c_lo = (a.nchunks * sub) >> 2, c_hi = (a.nchunks * (sub + 1)) >> 2;
+    for (int q = blockIdx.x * 64 + (threadIdx.x >> 2); q < total_q + ((a.n_valid + 3) & ~3); q += gridDim.x * 64) {
+        if (q < total_q) {
+            const int n = q / kq, k = (q - n * kq) * 4;
             const float *s = a.slab + (int64_t)(a.row0 + n) * a.KP + a.kc + k;
-            const int64_t stride = (int64_t)a.NP * a.KP;
-            // fixed summation order (deterministic): four interleaved partial sums, 8 loads in flight
-            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-            int c = 0;
-            for (; c + 8 <= a.nchunks; c += 8) {
-                float t[8];
+            f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+            int c = c_lo;
+            for (; c + 8 <= c_hi; c += 8) {
+                f32x4 t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = s[(c + u) * stride];
-                v0 += t[0]; v1 += t[1]; v2 += t[2]; v3 += t[3];
-                v0 += t[4]; v1 += t[5]; v2 += t[6]; v3 += t[7];
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4 *>(s + (c + u) * stride);
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { v0 += t[u]; v1 += t[u + 1]; }
             }
-            for (; c < a.nchunks; ++c) v0 += s[c * stride];
-            a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = (v0 + v1) + (v2 + v3);
-        } else if (a.dst_b) {
-            int n = e - total;
-            const float *s = a.slab + (int64_t)a.nchunks * a.NP * a.KP + a.row0 + n;
+            for (; c < c_hi; ++c) v0 += *reinterpret_cast<const f32x4 *>(s + c * stride);
+            v0 += v1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = v0[i];
+                x += __shfl_xor(x, 1);
+                x += __shfl_xor(x, 2);
+                v0[i] = x;
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = k + i;
+                    const int chan = (a.x_type == BLK_HIDDEN) ? (kk < a.k_valid ? kk : -1)
+                                                              : blk_chan(a.x_type, a.x_param, a.x_ks, kk & 1, kk >> 1);
+                    if (chan >= 0) a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = v0[i];
+                }
+            }
+        } else if (a.dst_b) {   // bias rows: one lane group per row
+            const int n = q - total_q;
             float v = 0.0f;
-            for (int c = 0; c < a.nchunks; ++c) v += s[(int64_t)c * a.NP];
-            a.dst_b[n] = v;
+            if (n < a.n_valid) {
+                const float *s = a.slab + (int64_t)a.nchunks * a.NP * a.KP + a.row0 + n;
+                for (int c = c_lo; c < c_hi; ++c) v += s[(int64_t)c * a.NP];
+            }
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (sub == 0 && n < a.n_valid) a.dst_b[n] = v;
         }
     }
 }
@@ -434,8 +456,8 @@ struct Bwd {
                 r.x_type = xp[q].type; r.x_param = xp[q].param; r.x_ks = xp[q].ks; r.k_valid = xp[q].k_valid;
                 r.kc = kc; r.kn = xp[q].tiles * 32;
                 kc += r.kn;
-                int total = r.n_valid * (r.kn + 1);
-                hipLaunchKernelGGL(reduce_unpack_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, r);
+                int total_q = r.n_valid * (r.kn / 4) + r.n_valid + 4;
+                hipLaunchKernelGGL(reduce_unpack_kernel, dim3(grid_for(total_q, 64, 4096)), dim3(256), 0, st, r);
             }
         }
         return check_launch("nrf_query_bwd (wgrad)");
