@@ -218,24 +218,61 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
     return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
 
 
+class _FrameDrain:
+    """Streaming of finished frames to the host: frame i's device->host copy, 8-bit quantisation and
+    PNG write happen after frame i+1's kernels have been enqueued, so the GPU never idles on host work.  The copy
+    goes through pinned memory on a side stream; the only host wait is on the event of the frame being drained."""
+
+    def __init__(self, savedir, depth=1):
+        self.savedir, self.depth = savedir, depth
+        self.pending, self.rgbs, self.disps = [], [], []
+        self.copy_stream = torch.cuda.Stream()
+
+    def push(self, i, rgb, disp):
+        ready = torch.cuda.Event()
+        ready.record()                                   # on the render stream: frame i is complete here
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ready)
+            h_rgb = torch.empty(rgb.shape, dtype=rgb.dtype, pin_memory=True)
+            h_disp = torch.empty(disp.shape, dtype=disp.dtype, pin_memory=True)
+            h_rgb.copy_(rgb, non_blocking=True)
+            h_disp.copy_(disp, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        self.pending.append((i, rgb, disp, h_rgb, h_disp, done))   # rgb/disp kept alive until the copy is done
+        while len(self.pending) > self.depth:
+            self._drain_one()
+
+    def _drain_one(self):
+        i, _, _, h_rgb, h_disp, done = self.pending.pop(0)
+        done.synchronize()
+        self.rgbs.append(h_rgb.numpy())
+        self.disps.append(h_disp.numpy())
+        if self.savedir is not None:
+            _write_png(os.path.join(self.savedir, '{:03d}.png'.format(i)), to8b(self.rgbs[-1]))
+
+    def finish(self):
+        while self.pending:
+            self._drain_one()
+        return np.stack(self.rgbs, 0), np.stack(self.disps, 0)
+
+
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
-    """One render() per pose -> (rgbs [N,H,W,3], disps [N,H,W]) as numpy; PNGs into savedir if given."""
+    """One render() per pose -> (rgbs [N,H,W,3], disps [N,H,W]) as numpy; PNGs into savedir if given.  Same results
+    as the reference's loop (render.py:347-366); host-side work of frame i overlaps the rendering of frame i+1."""
     H, W, focal = hwf
     if render_factor != 0:
         # NB: like the reference (render.py:337-341) K itself is not rescaled here
         H, W, focal = H // render_factor, W // render_factor, focal / render_factor
 
-    rgbs, disps = [], []
+    drain = _FrameDrain(savedir)
     t0 = time.time()
     for i, c2w in enumerate(render_poses):
         rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
+        drain.push(i, rgb, disp)
         if i == 0:
-            print(rgb.shape, disp.shape, f"first frame {time.time() - t0:.3f}s")
-        if savedir is not None:
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
-    return np.stack(rgbs, 0), np.stack(disps, 0)
+            print(rgb.shape, disp.shape, f"first frame enqueued after {time.time() - t0:.3f}s")
+    return drain.finish()
 
 
 def _write_png(path, rgb8):

@@ -16,7 +16,7 @@ import torch
 from .. import ops
 from ..positional_encoding import _EmbedFn
 from ..rays import get_rays  # noqa: F401  (same arithmetic as render.py:353-365)
-from ..render import _write_png, raw2outputs  # noqa: F401
+from ..render import _FrameDrain, _write_png, raw2outputs  # noqa: F401
 from ..sampling import sample_pdf  # noqa: F401
 from ..utils import DEBUG, to8b
 from .network import DNeRF_Deformation
@@ -214,17 +214,14 @@ def render_path_dnerf(render_poses, render_times, hwf, K, chunk, render_kwargs, 
         K[0, 2] = W / 2.
         K[1, 2] = H / 2.
 
-    rgbs, disps = [], []
+    drain = _FrameDrain(savedir)          # host-side work of frame i overlaps the rendering of frame i+1
     t0 = time.time()
     for i, (c2w, time_val) in enumerate(zip(render_poses, render_times)):
         if isinstance(time_val, torch.Tensor):
             time_val = time_val.item()
         rgb, disp, acc, _ = render_dnerf(H, W, K, time_val, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
+        drain.push(i, rgb, disp)
         if i == 0:
-            print(f"Render time: {time.time() - t0:.2f}s")
+            print(f"First frame enqueued after {time.time() - t0:.2f}s")
             print(f"RGB shape: {rgb.shape}, Disp shape: {disp.shape}")
-        if savedir is not None:
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
-    return np.stack(rgbs, 0), np.stack(disps, 0)
+    return drain.finish()

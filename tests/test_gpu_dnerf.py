@@ -225,3 +225,23 @@ def test_bf16_deformation_chain(gold_dnerf, parts):
     assert float((dx - dx_ref).abs().max()) < 1e-2 * max(sc, 1e-3), (float((dx - dx_ref).abs().max()), sc)
     rs = float(raw_ref.abs().max())
     assert float((raw - raw_ref).abs().max()) < 3e-2 * rs, (float((raw - raw_ref).abs().max()), rs)
+
+
+def test_render_path_dnerf(parts):
+    vd, model, qfn, _, _ = parts
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=32, perturb=0., N_importance=32, network_fine=None,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True, near=2., far=6.)
+    H = W = 8
+    K, focal = fx.intrinsics(H, W)
+    poses = torch.stack([dev(fx.pose_spherical(a, -30.0, 4.0)) for a in (0.0, 90.0, 180.0)])
+    times = torch.tensor([0.0, 0.5, 1.0])
+    with torch.no_grad():
+        rgbs, disps = vd.render_path_dnerf(poses, times, [H, W, focal], K, 1 << 15, kw)
+        assert rgbs.shape == (3, H, W, 3) and disps.shape == (3, H, W)
+        for i in range(3):
+            rgb, disp, _, _ = vd.render_dnerf(H, W, K, float(times[i]), chunk=1 << 15, c2w=poses[i, :3, :4], **kw)
+            assert np.array_equal(rgbs[i], host(rgb)) and np.array_equal(disps[i], host(disp))
+    # render_factor rescales K here (vanilla_dynamic/render.py:457-465), unlike the static render_path
+    with torch.no_grad():
+        r2, _ = vd.render_path_dnerf(poses[:1], times[:1], [H, W, focal], K, 1 << 15, kw, render_factor=2)
+    assert r2.shape == (1, H // 2, W // 2, 3)

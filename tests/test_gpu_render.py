@@ -192,3 +192,23 @@ def test_nerf_forward_embedded(gold):
     ref = gold["mlp_out_peaky"]
     np.testing.assert_allclose(host(out), ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
     assert sorted(net.state_dict()) == sorted(fx.make_nerf_state(12))
+
+
+def test_render_path_streams_frames(gold, nets, query_fn, tmp_path):
+    """render_path (render.py:318-371): per-pose render(), frames delivered as numpy in pose order; the streamed
+    device->host hand-off must not change a single value."""
+    from nerf_amd.render import render, render_path
+    coarse, fine = nets
+    kw = dict(network_query_fn=query_fn, perturb=0., N_importance=64, network_fine=fine, N_samples=32,
+              network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False,
+              near=2., far=6.)
+    H = W = 10
+    K, focal = fx.intrinsics(H, W)
+    poses = torch.stack([dev(fx.pose_spherical(a, -30.0, 4.0)) for a in (0.0, 40.0, 80.0, 120.0)])
+    with torch.no_grad():
+        rgbs, disps = render_path(poses, [H, W, focal], K, 64, kw, savedir=str(tmp_path))
+        assert rgbs.shape == (4, H, W, 3) and disps.shape == (4, H, W) and rgbs.dtype == np.float32
+        for i in range(4):
+            rgb, disp, _, _ = render(H, W, K, chunk=64, c2w=poses[i, :3, :4], **kw)
+            assert np.array_equal(rgbs[i], host(rgb)) and np.array_equal(disps[i], host(disp))
+    assert len(list(tmp_path.iterdir())) == 4          # one image (PNG, or .npy without imageio) per frame
