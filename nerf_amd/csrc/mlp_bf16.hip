@@ -28,6 +28,16 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 constexpr int kChunk = 16384;   // bytes per LDS stage: 16 A-fragments (one 32x16 bf16 tile = 1 KiB per wave load)
 constexpr int kFrag = 1024;
 
+#ifdef NRF_BF16_PROFILE
+static unsigned long long *g_prof_host_ptr = nullptr;
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0, t1)
+#endif
+
+
 // ---- channel maps (shared by the pack kernel and the query kernel) -----------------------------------
 // A k-step is one MFMA (16 input channels): lane half h supplies elements j = 0..7 (k = 8h + j).
 // Encoded inputs: lane half h owns a LOCAL list of 8*KS slots; k-step s takes slots 8s..8s+7.
@@ -224,25 +234,30 @@ struct WStream {
     int lane16, wave;
     bf16x8 q[kAhead];    // fragments in flight / ready: fragment i of a layer sits in q[i % kAhead]
 
+    // one of the four 1 KiB pieces this wave copies per chunk; the ring position advances after the last one
+    __device__ __forceinline__ void request_piece(int i) {
+        const uint32_t f = (uint32_t)wave + 4 * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + st_req + f * kFrag),
+                                                 16, lane16, (int)(pf_off + f * kFrag), 0, 0);
+        if (i == 3) {
+            pf_off += kChunk;
+            if (pf_off == total) pf_off = 0;
+            st_req += kChunk;
+            if (st_req == kStages * kChunk) st_req = 0;
+        }
+    }
     __device__ __forceinline__ void request() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t f = (uint32_t)wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + st_req + f * kFrag),
-                                                     16, lane16, (int)(pf_off + f * kFrag), 0, 0);
-        }
-        pf_off += kChunk;
-        if (pf_off == total) pf_off = 0;
-        st_req += kChunk;
-        if (st_req == kStages * kChunk) st_req = 0;
+        for (int i = 0; i < 4; ++i) request_piece(i);
     }
     // Mid-chunk: publish the NEXT chunk (own copies landed -> barrier -> everyone's landed, and everyone is past
-    // the previous chunk, whose stage the request for the chunk after next may now overwrite).
+    // the previous chunk, whose stage the copies of the chunk after next may now overwrite).  The caller then issues
+    // the four copies one at a time between MFMAs (each VMEM issue stalls the wave; spread out, the matrix pipe
+    // covers part of every stall instead of idling through four in a row).
     __device__ __forceinline__ void publish() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        request();
     }
     __device__ __forceinline__ void rotate() {
         rd_cur = rd_nxt;
@@ -282,6 +297,14 @@ __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st
         for (int f = 0; f < F; ++f) {
             const int i = 16 * c + f;
             if (f == pos) st.publish();
+            {   // copies of the chunk after next: one piece at each of four fragment slots from `pos` on
+                const int span = F - pos, stp = span >= 8 ? 2 : 1;
+                if (span >= 4) {
+                    if (f >= pos && (f - pos) % stp == 0 && (f - pos) / stp < 4) st.request_piece((f - pos) / stp);
+                } else if (f == pos) {
+                    st.request();
+                }
+            }
             const bf16x8 a = st.q[i % kAhead];
             {
                 const int j = i + kAhead;
@@ -361,10 +384,17 @@ __device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_
 // by the conversion of its outputs into the next layer's B fragments.
 template <int NT, int S0, class B0>
 __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v (&xin)[2][kBfKsX],
-                                         const u32x4v &one, WStream &st, int n_trunk, int skip_in_mask, B0 &&b0) {
+                                         const u32x4v &one, WStream &st, int n_trunk, int skip_in_mask, B0 &&b0,
+                                         long long *prof = nullptr) {
+    (void)prof;
+    PROF_T(t0);
     gemm_layer<NT, S0>(acc, st, b0);
+    PROF_T(t1);
     pack_acts<NT>(hin, acc, true);
+    PROF_T(t2);
+    PROF_ADD(1, t0, t1); PROF_ADD(2, t1, t2);
     for (int l = 1; l < n_trunk; ++l) {
+        PROF_T(t3);
         if ((skip_in_mask >> l) & 1)
             gemm_layer<NT, kBfKsX + 2 * NT>(acc, st, [&](int p, int s) {
                 return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
@@ -373,7 +403,10 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
             gemm_layer<NT, 2 * NT + 1>(acc, st, [&](int p, int s) {
                 return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
             });
+        PROF_T(t4);
         pack_acts<NT>(hin, acc, true);
+        PROF_T(t5);
+        PROF_ADD(1, t3, t4); PROF_ADD(2, t4, t5);
     }
 }
 
@@ -381,28 +414,39 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
 template <int NT>
 __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v &one, WStream &st,
                                               const float *hb, const float *viewdirs, const int64_t (&pp)[2],
-                                              const int64_t (&pc)[2], int64_t n_points, int pts_per_ray, int h, float *raw) {
+                                              const int64_t (&pc)[2], int64_t n_points, int pts_per_ray, int h, float *raw,
+                                              long long *prof = nullptr) {
+    (void)prof;
+    PROF_T(h0);
     auto Hb = [&](int p, int s) { return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one); };
     auto Hn = [&](int p, int s) { return as_bf(hin[p][s]); };
     f32x16 acc1[2][1];
     gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:56
     const float ab = hb[kHbAlpha];
     const float alpha0 = acc1[0][0][0] + ab, alpha1 = acc1[1][0][0] + ab;
+    PROF_T(h1);
+    PROF_ADD(5, h0, h1);
     gemm_layer<NT, 2 * NT + 1>(acc, st, Hb);                                               // network.py:57
     pack_acts<NT>(hin, acc, false);
+    PROF_T(h2);
     u32x4v din[2][kBfKsD];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const float *d = viewdirs + (pc[p] / pts_per_ray) * 3;
         fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
     }
+    PROF_T(h3);
+    PROF_ADD(6, h2, h3);
     f32x16 acc2[2][NT / 2];
     gemm_layer<NT / 2, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {                      // network.py:58-62
         return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
     });
     u32x4v hv[2][NT];
     pack_acts<NT / 2>(hv, acc2, true);
+    PROF_T(h4);
     gemm_layer<1, NT>(acc1, st, [&](int p, int s) { return as_bf(hv[p][s]); });            // network.py:64
+    PROF_T(h5);
+    PROF_ADD(7, h4, h5);
     if (h == 0) {
         const float b0 = hb[kHbRgb], b1 = hb[kHbRgb + 1], b2 = hb[kHbRgb + 2];
         if (pp[0] < n_points)
@@ -419,6 +463,7 @@ struct Bf16Args {
     float *raw;
     int64_t n_points;
     int32_t pts_per_ray, n_trunk, skip_in_mask, use_viewdirs, output_ch, dbg, pad_[2];
+    unsigned long long *prof_out;
 };
 
 
@@ -439,7 +484,14 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
     u32x4v one;   // the constant-1 channel of a bias k-step: element 0 of lane half 0
     one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
 
+#ifdef NRF_BF16_PROFILE
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk0 = clock64();
+#else
+    long long *prof = nullptr;
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        PROF_T(ta);
         int64_t pp[2], pc[2];
         u32x4v xin[2][kBfKsX];
 #pragma unroll
@@ -449,12 +501,17 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
             const float *q = a.pts + pc[p] * 3;
             fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], h);
         }
+        PROF_T(tb);
+        PROF_ADD(0, ta, tb);
         f32x16 acc[2][NT];
         u32x4v hin[2][2 * NT];
         bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.n_trunk, a.skip_in_mask,
-                             [&](int p, int s) { return as_bf(xin[p][s]); });                     // network.py:48-53
+                             [&](int p, int s) { return as_bf(xin[p][s]); }, prof);               // network.py:48-53
+        PROF_T(tc);
         if (a.use_viewdirs) {
-            bf_views_head<NT>(acc, hin, one, st, hb, a.viewdirs, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
+            bf_views_head<NT>(acc, hin, one, st, hb, a.viewdirs, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
+            PROF_T(td);
+            PROF_ADD(3, tc, td);
         } else {
             f32x16 acc1[2][1];
             gemm_layer<1, 2 * NT>(acc1, st, [&](int p, int s) { return as_bf(hin[p][s]); });       // network.py:67
@@ -469,6 +526,12 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests in flight must land before the LDS is released
     __builtin_amdgcn_s_barrier();
+#ifdef NRF_BF16_PROFILE
+    if (threadIdx.x == 0 && a.prof_out) {
+        prof[4] = clock64() - tk0;
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.prof_out[i], (unsigned long long)prof[i]);
+    }
+#endif
 }
 
 // gamma(t) of a scalar into KS k-step fragments (slot order of bf_pe1_chan)
@@ -684,6 +747,9 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
     a.skip_in_mask = 0;
     for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
     a.use_viewdirs = net->use_viewdirs; a.output_ch = net->output_ch;
+#ifdef NRF_BF16_PROFILE
+    a.prof_out = nrf::g_prof_host_ptr;
+#endif
     if (const char *d = getenv("NRF_BF16_DEBUG")) a.dbg = atoi(d);   // timing experiments only (1: drop the weight DMA)
     const int64_t ntiles = (n_points + 255) / 256;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);   // 512 registers per lane: one workgroup per CU
@@ -695,3 +761,7 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
     }
     return check_launch("nrf_query_fwd_bf16");
 }
+
+#ifdef NRF_BF16_PROFILE
+extern "C" int nrf_bf16_profile_set(unsigned long long *device_counters) { nrf::g_prof_host_ptr = device_counters; return 0; }
+#endif
