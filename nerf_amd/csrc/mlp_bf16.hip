@@ -413,7 +413,7 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
 // View-direction head of the canonical net (network.py:56-65) -> (rgb + alpha) of both point tiles, stored by lane half 0.
 template <int NT>
 __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v &one, WStream &st,
-                                              const float *hb, const float *viewdirs, const int64_t (&pp)[2],
+                                              const float *hb, const float (&dv)[2][3], const int64_t (&pp)[2],
                                               const int64_t (&pc)[2], int64_t n_points, int pts_per_ray, int h, float *raw,
                                               long long *prof = nullptr) {
     (void)prof;
@@ -431,10 +431,7 @@ __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin
     PROF_T(h2);
     u32x4v din[2][kBfKsD];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float *d = viewdirs + (pc[p] / pts_per_ray) * 3;
-        fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
-    }
+    for (int p = 0; p < 2; ++p) fill_pe3_bf16<kBfKsD>(din[p], dv[p][0], dv[p][1], dv[p][2], h);
     PROF_T(h3);
     PROF_ADD(6, h2, h3);
     f32x16 acc2[2][NT / 2];
@@ -493,12 +490,17 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         PROF_T(ta);
         int64_t pp[2], pc[2];
+        float dv[2][3] = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}};
         u32x4v xin[2][kBfKsX];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             pp[p] = tile * 256 + st.wave * 64 + p * 32 + n;
             pc[p] = pp[p] < a.n_points ? pp[p] : a.n_points - 1;
             const float *q = a.pts + pc[p] * 3;
+            if (a.use_viewdirs) {   // issued here, used after the trunk: the load's latency disappears behind it
+                const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
+                dv[p][0] = d[0]; dv[p][1] = d[1]; dv[p][2] = d[2];
+            }
             fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], h);
         }
         PROF_T(tb);
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
                              [&](int p, int s) { return as_bf(xin[p][s]); }, prof);               // network.py:48-53
         PROF_T(tc);
         if (a.use_viewdirs) {
-            bf_views_head<NT>(acc, hin, one, st, hb, a.viewdirs, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
+            bf_views_head<NT>(acc, hin, one, st, hb, dv, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
             PROF_T(td);
             PROF_ADD(3, tc, td);
         } else {
@@ -591,7 +593,7 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const Dner
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int64_t pp[2], pc[2];
-        float px[2][3];
+        float px[2][3], dv[2][3];
         bool skip[2];
         u32x4v xin[2][kBfKsX], tin[2][kBfKsT];
 #pragma unroll
@@ -602,6 +604,8 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const Dner
             px[p][0] = q[0]; px[p][1] = q[1]; px[p][2] = q[2];
             const int64_t chunk_first = (pc[p] / a.netchunk) * a.netchunk;       // network.py:315-322
             skip[p] = a.zero_canonical && a.times[chunk_first / a.t_div] == 0.0f;
+            const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
+            dv[p][0] = d[0]; dv[p][1] = d[1]; dv[p][2] = d[2];
             fill_pe3_bf16<kBfKsX>(xin[p], px[p][0], px[p][1], px[p][2], h);
             fill_pe1_bf16<kBfKsT>(tin[p], a.times[pc[p] / a.t_div], h);
         }
@@ -631,7 +635,7 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const Dner
             }
         }
         bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.c_trunk, a.c_skip_mask, [&](int p, int s) { return as_bf(xin[p][s]); });
-        bf_views_head<NT>(acc, hin, one, st, hb, a.viewdirs, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
+        bf_views_head<NT>(acc, hin, one, st, hb, dv, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
