@@ -178,7 +178,7 @@ extern "C" int nrf_composite_fwd(const float *raw, const float *z_vals, const fl
                                  int64_t n_rays, int32_t n_samples, const float *noise, int32_t white_bkgd,
                                  float *rgb_map, float *disp_map, float *acc_map, float *weights, float *depth_map,
                                  void *stream) {
-    NRF_REQUIRE(raw && z_vals && rays_d && rgb_map && disp_map && acc_map && weights && depth_map,
+    if (n_rays != 0) NRF_REQUIRE(raw && z_vals && rays_d && rgb_map && disp_map && acc_map && weights && depth_map,
                 "nrf_composite_fwd: null pointer");
     NRF_REQUIRE(n_rays >= 0 && n_samples >= 1 && d_stride >= 3, "nrf_composite_fwd: bad sizes");
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(raw) & 15) == 0, "nrf_composite_fwd: raw must be 16-byte aligned");
@@ -193,7 +193,7 @@ extern "C" int nrf_composite_bwd(const float *raw, const float *z_vals, const fl
                                  int64_t n_rays, int32_t n_samples, const float *noise, int32_t white_bkgd,
                                  const float *g_rgb, const float *g_acc, const float *g_depth,
                                  const float *g_weights, float *g_raw, void *stream) {
-    NRF_REQUIRE(raw && z_vals && rays_d && g_rgb && g_raw, "nrf_composite_bwd: null pointer");
+    if (n_rays != 0) NRF_REQUIRE(raw && z_vals && rays_d && g_rgb && g_raw, "nrf_composite_bwd: null pointer");
     NRF_REQUIRE(n_rays >= 0 && n_samples >= 1 && d_stride >= 3, "nrf_composite_bwd: bad sizes");
     NRF_REQUIRE(((reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(g_raw)) & 15) == 0,
                 "nrf_composite_bwd: raw/g_raw must be 16-byte aligned");

@@ -683,7 +683,8 @@ extern "C" int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net
                                         const void *packed, const float *pts, const float *viewdirs, const float *times,
                                         int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
                                         int32_t zero_canonical, float *raw, float *dx, void *stream) {
-    NRF_REQUIRE(time_net && occ_net && emb && packed && pts && viewdirs && times && raw && dx,
+    NRF_REQUIRE(time_net && occ_net && emb, "nrf_dnerf_query_fwd_bf16: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(time_net && occ_net && emb && packed && pts && viewdirs && times && raw && dx,
                 "nrf_dnerf_query_fwd_bf16: null pointer");
     NRF_REQUIRE(n_points >= 0 && pts_per_ray >= 1 && netchunk >= 1, "nrf_dnerf_query_fwd_bf16: bad sizes");
     NRF_REQUIRE(n_points % pts_per_ray == 0, "nrf_dnerf_query_fwd_bf16: n_points must be a multiple of pts_per_ray");
@@ -730,12 +731,13 @@ extern "C" int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t
 
 extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
                                   const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
-    NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd_bf16: null pointer");
+    NRF_REQUIRE(net && emb, "nrf_query_fwd_bf16: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd_bf16: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_fwd_bf16: negative n_points");
     if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd_bf16: %s", e);
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
                 "nrf_query_fwd_bf16: packed and raw must be 16-byte aligned");
-    if (net->use_viewdirs) {
+    if (net->use_viewdirs && n_points != 0) {
         NRF_REQUIRE(viewdirs, "nrf_query_fwd_bf16: viewdirs is null but the net uses view directions");
         NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0,
                     "nrf_query_fwd_bf16: n_points (%lld) must be a multiple of pts_per_ray (%d)", (long long)n_points, pts_per_ray);

@@ -493,7 +493,8 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                           const nrf_net_t *grads, const float *pts, float *g_pts, void *stream) {
-    NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
+    NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
     Planner P{};
     const char *e = plan_net(P, net, emb, time_ch);

@@ -145,7 +145,8 @@ extern "C" int nrf_dnerf_query_fwd(const nrf_net_t *time_net, const nrf_net_t *o
                                    const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
                                    int32_t times_per_point, int64_t netchunk, int32_t zero_canonical, float *raw,
                                    float *dx, void *stream) {
-    NRF_REQUIRE(time_net && occ_net && emb && packed_time && packed_occ && pts && viewdirs && times && raw && dx,
+    NRF_REQUIRE(time_net && occ_net && emb, "nrf_dnerf_query_fwd: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(time_net && occ_net && emb && packed_time && packed_occ && pts && viewdirs && times && raw && dx,
                 "nrf_dnerf_query_fwd: null pointer");
     NRF_REQUIRE(n_points >= 0 && pts_per_ray >= 1 && netchunk >= 1, "nrf_dnerf_query_fwd: bad sizes");
     NRF_REQUIRE(n_points % pts_per_ray == 0, "nrf_dnerf_query_fwd: n_points must be a multiple of pts_per_ray");

@@ -176,7 +176,8 @@ extern "C" int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb
 static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
                           const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
                           void *stream, const float *times = nullptr, int64_t t_div = 1) {
-    NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd: null pointer");
+    NRF_REQUIRE(net && emb, "nrf_query_fwd: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_fwd: negative n_points");
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
                 "nrf_query_fwd: packed and raw must be 16-byte aligned");
@@ -190,7 +191,7 @@ static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const fl
     a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.raw = raw; a.n_points = n_points;
     a.input_ch = net->input_ch;
     a.x_stride = net->input_ch + net->input_ch_views;
-    if (emb->mode == 0 && P.plan.use_viewdirs) {
+    if (emb->mode == 0 && P.plan.use_viewdirs && n_points != 0) {
         NRF_REQUIRE(viewdirs, "nrf_query_fwd: viewdirs is null but the net uses view directions");
         NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0,
                     "nrf_query_fwd: n_points (%lld) must be a multiple of pts_per_ray (%d)", (long long)n_points,
@@ -234,7 +235,8 @@ extern "C" int nrf_query_fwd_train(const nrf_net_t *net, const nrf_embed_t *emb,
 extern "C" int nrf_dnerf_time_fwd_train(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
                                         const float *pts, const float *times, int64_t n_points, int32_t pts_per_ray,
                                         int32_t times_per_point, float *dx, float *acts, void *stream) {
-    NRF_REQUIRE(time_net && emb && times && acts && dx, "nrf_dnerf_time_fwd_train: null pointer");
+    NRF_REQUIRE(time_net && emb, "nrf_dnerf_time_fwd_train: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(time_net && emb && times && acts && dx, "nrf_dnerf_time_fwd_train: null pointer");
     NRF_REQUIRE(emb->mode == 0 && !time_net->use_viewdirs, "nrf_dnerf_time_fwd_train: needs embed mode 0 and a time-net descriptor");
     NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0, "nrf_dnerf_time_fwd_train: n_points must be a multiple of pts_per_ray");
     return query_fwd_impl(time_net, emb, packed_time, pts, nullptr, n_points, pts_per_ray, dx, acts, stream, times,

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) pe_fwd_kernel(const float *__restrict__ x
 
 extern "C" int nrf_pe_fwd(const float *x, int64_t n_points, int32_t dims, int32_t num_freqs, float max_freq_log2,
                           int32_t log_sampling, int32_t include_input, float *out, void *stream) {
-    NRF_REQUIRE(x && out, "nrf_pe_fwd: null pointer");
+    if (n_points != 0) NRF_REQUIRE(x && out, "nrf_pe_fwd: null pointer");
     NRF_REQUIRE(n_points >= 0 && dims >= 1 && num_freqs >= 0, "nrf_pe_fwd: bad sizes");
     int out_dim = dims * ((include_input ? 1 : 0) + 2 * num_freqs);
     NRF_REQUIRE(out_dim > 0, "nrf_pe_fwd: empty embedding");

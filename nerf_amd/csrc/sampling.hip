@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
 
 extern "C" int nrf_sample_coarse(const float *rays, int64_t n_rays, int32_t ncol, int32_t n_samples,
                                  int32_t lindisp, const float *t_rand, float *z_vals, void *stream) {
-    NRF_REQUIRE(rays && z_vals, "nrf_sample_coarse: null pointer");
+    if (n_rays != 0) NRF_REQUIRE(rays && z_vals, "nrf_sample_coarse: null pointer");
     NRF_REQUIRE(n_rays >= 0 && ncol >= 8 && n_samples >= 1, "nrf_sample_coarse: bad sizes (n_rays=%lld ncol=%d S=%d)",
                 (long long)n_rays, ncol, n_samples);
     if (n_rays == 0) return NRF_OK;
@@ -261,7 +261,7 @@ extern "C" int nrf_sample_coarse(const float *rays, int64_t n_rays, int32_t ncol
 
 extern "C" int nrf_points(const float *rays, int64_t n_rays, int32_t ncol, const float *z_vals, int32_t n_samples,
                           float *pts, void *stream) {
-    NRF_REQUIRE(rays && z_vals && pts, "nrf_points: null pointer");
+    if (n_rays != 0) NRF_REQUIRE(rays && z_vals && pts, "nrf_points: null pointer");
     NRF_REQUIRE(n_rays >= 0 && ncol >= 6 && n_samples >= 1, "nrf_points: bad sizes");
     if (n_rays == 0) return NRF_OK;
     int64_t total = n_rays * n_samples * 3;
@@ -273,7 +273,7 @@ extern "C" int nrf_points(const float *rays, int64_t n_rays, int32_t ncol, const
 extern "C" int nrf_sample_fine(const float *z_vals, const float *weights, int64_t n_rays, int32_t n_samples,
                                int32_t n_importance, const float *u, float *z_samples, float *z_merged,
                                float *z_std, void *stream) {
-    NRF_REQUIRE(z_vals && weights && z_merged, "nrf_sample_fine: null pointer");
+    if (n_rays != 0) NRF_REQUIRE(z_vals && weights && z_merged, "nrf_sample_fine: null pointer");
     NRF_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1, "nrf_sample_fine: bad sizes");
     if (n_samples - 1 > kMaxBins || n_samples + n_importance > kMaxMerged)
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_fine: N_samples-1 <= %d and N_samples+N_importance <= %d",
@@ -286,7 +286,7 @@ extern "C" int nrf_sample_fine(const float *z_vals, const float *weights, int64_
 
 extern "C" int nrf_sample_pdf(const float *bins, const float *weights, int64_t n_rows, int32_t n_bins,
                               int32_t n_samples, const float *u, float *samples, void *stream) {
-    NRF_REQUIRE(bins && weights && samples, "nrf_sample_pdf: null pointer");
+    if (n_rows != 0) NRF_REQUIRE(bins && weights && samples, "nrf_sample_pdf: null pointer");
     NRF_REQUIRE(n_rows >= 0 && n_bins >= 2 && n_samples >= 1, "nrf_sample_pdf: bad sizes");
     if (n_bins > kMaxBins || n_samples > kMaxMerged)
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_pdf: n_bins <= %d, n_samples <= %d", kMaxBins, kMaxMerged);
