@@ -42,6 +42,7 @@ def parse():
                     help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
     ap.add_argument("--train-rays", type=int, default=4096, help="global ray batch of the train workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-path", action="store_true", help="use the multi-GPU row-sharded code path even with one GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the short secondary measurements (N=1 only)")
     ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -261,15 +262,13 @@ def main():
         else:
             c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
         with torch.no_grad():
-            if world == 1:
+            if world == 1 and not args.sharded_path:
                 rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=near, far=far, **kw)
                 return rgb
-            ro_full, rd_full = get_rays(H, W, K, c2w)
-
             def rows(row0, nrows):
-                rays = torch.stack([ro_full[row0:row0 + nrows].reshape(-1, 3), rd_full[row0:row0 + nrows].reshape(-1, 3)])
-                rgb, disp, acc, _ = render(H, W, K, chunk=32768, rays=rays, near=near, far=far, **kw)
-                return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+                kw2 = {k: v for k, v in kw.items() if k not in ("ndc", "use_viewdirs")}
+                return parallel.render_rows(H, W, K, c2w, row0, nrows, chunk=32768, ndc=kw["ndc"], near=near, far=far,
+                                            use_viewdirs=True, **kw2)
             return parallel.render_sharded(rows, H, W, rank, world)
 
     def fence():

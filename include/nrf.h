@@ -57,6 +57,14 @@ typedef struct {
     int32_t multires_time;   /* D-NeRF time embedding L (vanilla_dynamic/positional_encoding.py:71-97) */
 } nrf_embed_t;
 
+/* K0  ray matrix of render() from (rows of the image, intrinsics, pose) -- rays.py:5-27 (get_rays), render.py:283-290
+ * (viewdirs; c2w_static = the camera when c2w_staticcam is given, may be NULL), rays.py:52-83 (ndc_rays),
+ * render.py:298-304 (bounds).  c2w / c2w_static: DEVICE pointers to 3 rows of >= 4 floats, `stride` floats apart.
+ * rays [nrows * W, use_viewdirs ? 11 : 8], rows row0 .. row0+nrows-1 of the H x W image. */
+int nrf_gen_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float *c2w, int32_t c2w_stride,
+                 const float *c2w_static, int32_t static_stride, int32_t row0, int32_t nrows, float near, float far,
+                 int32_t use_viewdirs, int32_t ndc, float ndc_focal, float ndc_near, float *rays, void *stream);
+
 /* K1  coarse depths  -- render.py:186-208 (linspace, near/far lerp or lindisp, optional stratified jitter)
  * rays [N, ncol] = o(3) d(3) near far [viewdirs(3)]  (render.py:181-184); t_rand: NULL (perturb == 0) or
  * [N, S] uniform randoms (render.py:200-206).  z_vals [N, S].  Bit-exact with the reference for perturb==0. */

@@ -247,6 +247,83 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
 
 }  // namespace
 
+// K0: the [N, 8|11] ray matrix of render() straight from (pixel range, intrinsics, pose) --
+// get_rays rays.py:5-27, viewdirs render.py:283-290, ndc_rays rays.py:52-83, bounds render.py:298-304 -- one
+// thread per ray, the reference's f32 operation order (this file is built with -ffp-contract=off).
+struct GenRaysArgs {
+    const float *c2w, *c2w_static;   // device, rows of `stride` floats ([:3, :4] views); static may be null
+    int32_t stride, stride_static;
+    int32_t H, W, row0, nrows;
+    float fx, fy, cx, cy;
+    float near, far;
+    int32_t use_viewdirs, ndc;
+    float ndc_focal, ndc_near;
+    float *rays;                     // [nrows * W, 8 | 11]
+};
+
+__device__ __forceinline__ void pose_ray(const float *m, int stride, float x, float y, float (&o)[3], float (&d)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *r = m + k * stride;
+        // torch.sum(dirs[..., None, :] * c2w[:3, :3], -1): rounded products, summed left to right; dirs_z = -1
+        d[k] = __fadd_rn(__fadd_rn(__fmul_rn(x, r[0]), __fmul_rn(y, r[1])), __fmul_rn(-1.0f, r[2]));
+        o[k] = r[3];
+    }
+}
+
+__global__ void __launch_bounds__(256) gen_rays_kernel(const GenRaysArgs a) {
+    const int64_t total = (int64_t)a.nrows * a.W;
+    const int ncol = a.use_viewdirs ? 11 : 8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int row = a.row0 + (int)(e / a.W), col = (int)(e % a.W);
+        const float x = __fdiv_rn(__fsub_rn((float)col, a.cx), a.fx);
+        const float y = __fdiv_rn(-__fsub_rn((float)row, a.cy), a.fy);
+        float o[3], d[3], v[3] = {0.f, 0.f, 0.f};
+        pose_ray(a.c2w, a.stride, x, y, o, d);
+        if (a.use_viewdirs) {   // view directions come from c2w even when the camera is c2w_staticcam
+            const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+            v[0] = __fdiv_rn(d[0], nrm); v[1] = __fdiv_rn(d[1], nrm); v[2] = __fdiv_rn(d[2], nrm);
+            if (a.c2w_static) pose_ray(a.c2w_static, a.stride_static, x, y, o, d);
+        }
+        if (a.ndc) {            // rays.py:66-78
+            const float t = __fdiv_rn(-__fadd_rn(a.ndc_near, o[2]), d[2]);
+            o[0] = __fadd_rn(o[0], __fmul_rn(t, d[0]));
+            o[1] = __fadd_rn(o[1], __fmul_rn(t, d[1]));
+            o[2] = __fadd_rn(o[2], __fmul_rn(t, d[2]));
+            const float sx = (float)(-1.0 / ((double)a.W / (2.0 * (double)a.ndc_focal)));
+            const float sy = (float)(-1.0 / ((double)a.H / (2.0 * (double)a.ndc_focal)));
+            const float tn = (float)(2.0 * (double)a.ndc_near);
+            const float o0 = __fdiv_rn(__fmul_rn(sx, o[0]), o[2]);
+            const float o1 = __fdiv_rn(__fmul_rn(sy, o[1]), o[2]);
+            const float o2 = __fadd_rn(1.0f, __fdiv_rn(tn, o[2]));
+            const float d0 = __fmul_rn(sx, __fsub_rn(__fdiv_rn(d[0], d[2]), __fdiv_rn(o[0], o[2])));
+            const float d1 = __fmul_rn(sy, __fsub_rn(__fdiv_rn(d[1], d[2]), __fdiv_rn(o[1], o[2])));
+            const float d2 = __fdiv_rn(-tn, o[2]);
+            o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
+        }
+        float *r = a.rays + e * ncol;
+        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2]; r[6] = a.near; r[7] = a.far;
+        if (a.use_viewdirs) { r[8] = v[0]; r[9] = v[1]; r[10] = v[2]; }
+    }
+}
+
+extern "C" int nrf_gen_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float *c2w, int32_t c2w_stride,
+                            const float *c2w_static, int32_t static_stride, int32_t row0, int32_t nrows, float near,
+                            float far, int32_t use_viewdirs, int32_t ndc, float ndc_focal, float ndc_near, float *rays,
+                            void *stream) {
+    NRF_REQUIRE(H >= 1 && W >= 1 && row0 >= 0 && nrows >= 0 && row0 + nrows <= H, "nrf_gen_rays: bad image / row range");
+    NRF_REQUIRE(c2w_stride >= 4 && (!c2w_static || static_stride >= 4), "nrf_gen_rays: pose rows need >= 4 floats");
+    if (nrows == 0) return NRF_OK;
+    NRF_REQUIRE(c2w && rays, "nrf_gen_rays: null pointer");
+    GenRaysArgs a{};
+    a.c2w = c2w; a.c2w_static = use_viewdirs ? c2w_static : nullptr; a.stride = c2w_stride; a.stride_static = static_stride;
+    a.H = H; a.W = W; a.row0 = row0; a.nrows = nrows; a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
+    a.near = near; a.far = far; a.use_viewdirs = use_viewdirs; a.ndc = ndc; a.ndc_focal = ndc_focal; a.ndc_near = ndc_near;
+    a.rays = rays;
+    hipLaunchKernelGGL(gen_rays_kernel, dim3(nrf::grid_for((int64_t)nrows * W, 256)), dim3(256), 0, nrf::as_stream(stream), a);
+    return nrf::check_launch("nrf_gen_rays");
+}
+
 extern "C" int nrf_sample_coarse(const float *rays, int64_t n_rays, int32_t ncol, int32_t n_samples,
                                  int32_t lindisp, const float *t_rand, float *z_vals, void *stream) {
     if (n_rays != 0) NRF_REQUIRE(rays && z_vals, "nrf_sample_coarse: null pointer");

@@ -29,6 +29,28 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+# ---------------------------------------------------------------- rays
+def _pose_rows(c2w):
+    """[>=3, >=4] pose tensor -> (tensor kept alive, row stride) with unit column stride."""
+    c2w = _f32(c2w, "c2w") if c2w.stride(-1) != 1 or c2w.dtype != torch.float32 or not c2w.is_cuda else c2w
+    return c2w, int(c2w.stride(0))
+
+
+def gen_rays(H, W, K, c2w, near, far, use_viewdirs, ndc, c2w_staticcam=None, row0=0, nrows=None, ndc_near=1.0):
+    """The [N, 8|11] ray matrix render() feeds to render_rays, for image rows row0 .. row0+nrows-1 (one kernel)."""
+    nrows = H - row0 if nrows is None else nrows
+    c2w, stride = _pose_rows(c2w)
+    cs, cs_stride = (None, 4)
+    if c2w_staticcam is not None and use_viewdirs:
+        cs, cs_stride = _pose_rows(c2w_staticcam)
+    rays = torch.empty((nrows * W, 11 if use_viewdirs else 8), device=c2w.device, dtype=torch.float32)
+    check(_lib.lib().nrf_gen_rays(int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                                  _ptr(c2w), stride, _ptr(cs), cs_stride, int(row0), int(nrows), float(near), float(far),
+                                  int(bool(use_viewdirs)), int(bool(ndc)), float(K[0][0]), float(ndc_near), _ptr(rays),
+                                  _stream()), "nrf_gen_rays")
+    return rays
+
+
 # ---------------------------------------------------------------- sampling
 def sample_coarse(rays, n_samples, lindisp=False, t_rand=None):
     """render.py:186-208 -> z_vals [N, S]."""

@@ -47,6 +47,17 @@ def render_sharded(render_rows, H, W, rank=None, world=None, group=None):
     return torch.cat([g[: n * W] for g, (_, n) in zip(gathered, parts)], 0).reshape(H, W, C)
 
 
+def render_rows(H, W, K, c2w, row0, nrows, chunk=1024 * 32, ndc=True, near=0., far=1., use_viewdirs=False,
+                c2w_staticcam=None, **kwargs):
+    """Rows row0 .. row0+nrows-1 of render(H, W, K, c2w=...) as one [nrows*W, 5] tensor (rgb, disp, acc): a rank's
+    share of an image is a pure (row range, pose, intrinsics) descriptor -- no ray data is moved between ranks."""
+    from . import ops
+    from .render import batchify_rays
+    ray_matrix = ops.gen_rays(H, W, K, c2w, near, far, use_viewdirs, ndc, c2w_staticcam, row0=row0, nrows=nrows)
+    ret = batchify_rays(ray_matrix, chunk, **kwargs)
+    return torch.cat([ret['rgb_map'], ret['disp_map'][:, None], ret['acc_map'][:, None]], -1)
+
+
 class FlatGradAllReduce:
     """Averages the gradients of `params` over the ranks with ONE all-reduce of a flat buffer."""
 

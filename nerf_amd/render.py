@@ -182,11 +182,8 @@ def render_rays(ray_batch,
     return ret
 
 
-def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
-           near=0., far=1.,
-           use_viewdirs=False, c2w_staticcam=None,
-           **kwargs):
-    """Full image (c2w given) or an explicit ray batch rays=[2, N, 3] -> [rgb, disp, acc, extras]."""
+def _ray_matrix_torch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam):
+    """render.py:276-304 with torch ops: explicit ray batches (training) and host-side poses."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, K, c2w)
     else:
@@ -208,7 +205,20 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
     near_t = near * torch.ones_like(rays_d[..., :1])
     far_t = far * torch.ones_like(rays_d[..., :1])
     cols = [rays_o, rays_d, near_t, far_t] + ([viewdirs] if use_viewdirs else [])
-    ray_matrix = torch.cat(cols, -1)
+    return torch.cat(cols, -1), sh
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
+           near=0., far=1.,
+           use_viewdirs=False, c2w_staticcam=None,
+           **kwargs):
+    """Full image (c2w given) or an explicit ray batch rays=[2, N, 3] -> [rgb, disp, acc, extras]."""
+    if c2w is not None and isinstance(c2w, torch.Tensor) and c2w.is_cuda:
+        # whole-image case: the ray matrix comes from one kernel (get_rays + viewdirs + NDC + bounds fused)
+        ray_matrix = ops.gen_rays(H, W, K, c2w, near, far, use_viewdirs, ndc, c2w_staticcam)
+        sh = (H, W, 3)
+    else:
+        ray_matrix, sh = _ray_matrix_torch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam)
 
     all_ret = batchify_rays(ray_matrix, chunk, **kwargs)
     for k in all_ret:

@@ -168,32 +168,35 @@ def batchify_rays_dnerf(rays_flat, time_vals, chunk=1024 * 32, **kwargs):
 def render_dnerf(H, W, K, time_vals, chunk=1024 * 32, rays=None, c2w=None,
                  near=0., far=1., use_viewdirs=False, c2w_staticcam=None, **kwargs):
     """time_vals: scalar or per-ray tensor -> [rgb, disp, acc, extras]."""
-    if c2w is not None:
-        rays_o, rays_d = get_rays(H, W, K, c2w)
+    if c2w is not None and isinstance(c2w, torch.Tensor) and c2w.is_cuda:
+        ray_matrix = ops.gen_rays(H, W, K, c2w, near, far, use_viewdirs, False, c2w_staticcam)   # one kernel
+        sh = (H, W, 3)
     else:
-        rays_o, rays_d = rays
-    if use_viewdirs:
-        viewdirs = rays_d
-        if c2w_staticcam is not None:
-            rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
-        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
-        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+        if c2w is not None:
+            rays_o, rays_d = get_rays(H, W, K, c2w)
+        else:
+            rays_o, rays_d = rays
+        if use_viewdirs:
+            viewdirs = rays_d
+            if c2w_staticcam is not None:
+                rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+            viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+            viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+        sh = rays_d.shape
+        rays_o = torch.reshape(rays_o, [-1, 3]).float()
+        rays_d = torch.reshape(rays_d, [-1, 3]).float()
+        near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+        ray_matrix = torch.cat([rays_o, rays_d, near_t, far_t] + ([viewdirs] if use_viewdirs else []), -1)
 
-    sh = rays_d.shape
-    rays_o = torch.reshape(rays_o, [-1, 3]).float()
-    rays_d = torch.reshape(rays_d, [-1, 3]).float()
-
-    n_rays = rays_o.shape[0]
+    n_rays = ray_matrix.shape[0]
     if isinstance(time_vals, torch.Tensor):
-        time_vals_flat = time_vals.reshape(-1, 1).float().to(rays_o.device)
+        time_vals_flat = time_vals.reshape(-1, 1).float().to(ray_matrix.device)
         if time_vals_flat.shape[0] != n_rays:   # wrong count: the reference broadcasts the mean (render.py:414-416)
-            time_vals_flat = torch.ones(n_rays, 1, device=rays_o.device) * time_vals_flat.mean()
+            time_vals_flat = torch.ones(n_rays, 1, device=ray_matrix.device) * time_vals_flat.mean()
     else:
-        time_vals_flat = torch.ones(n_rays, 1, device=rays_o.device) * float(time_vals)
+        time_vals_flat = torch.ones(n_rays, 1, device=ray_matrix.device) * float(time_vals)
 
-    near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
-    cols = [rays_o, rays_d, near_t, far_t] + ([viewdirs] if use_viewdirs else [])
-    all_ret = batchify_rays_dnerf(torch.cat(cols, -1), time_vals_flat, chunk, **kwargs)
+    all_ret = batchify_rays_dnerf(ray_matrix, time_vals_flat, chunk, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
 

@@ -212,3 +212,37 @@ def test_render_path_streams_frames(gold, nets, query_fn, tmp_path):
             rgb, disp, _, _ = render(H, W, K, chunk=64, c2w=poses[i, :3, :4], **kw)
             assert np.array_equal(rgbs[i], host(rgb)) and np.array_equal(disps[i], host(disp))
     assert len(list(tmp_path.iterdir())) == 4          # one image (PNG, or .npy without imageio) per frame
+
+
+def test_fused_ray_matrix(gold):
+    """nrf_gen_rays (get_rays + viewdirs + ndc_rays + bounds in one kernel) against the torch-op composition and
+    the reference's goldens: origins exact, directions / view directions to 1 ulp-scale (1e-7 relative)."""
+    from nerf_amd import ops
+    from nerf_amd.render import _ray_matrix_torch
+    cases = [
+        dict(H=12, W=12, K=gold["render_blender_K"], c2w=gold["render_blender_c2w"], ndc=False, near=2., far=6., vd=True, st=None),
+        dict(H=9, W=12, K=gold["render_ndc_K"], c2w=gold["render_ndc_c2w"], ndc=True, near=0., far=1., vd=True, st=None),
+        dict(H=6, W=6, K=fx.intrinsics(6, 6)[0], c2w=gold["render_blender_c2w"], ndc=False, near=2., far=6., vd=True,
+             st=gold["render_static_c2w"]),
+        dict(H=7, W=5, K=fx.intrinsics(7, 5)[0], c2w=gold["render_blender_c2w"], ndc=False, near=1., far=3., vd=False, st=None),
+    ]
+    for c in cases:
+        c2w = dev(c["c2w"])
+        st = dev(c["st"]) if c["st"] is not None else None
+        got = ops.gen_rays(c["H"], c["W"], c["K"], c2w, c["near"], c["far"], c["vd"], c["ndc"], st)
+        ref, sh = _ray_matrix_torch(c["H"], c["W"], c["K"], None, c2w, c["ndc"], c["near"], c["far"], c["vd"], st)
+        assert got.shape == ref.shape and tuple(sh) == (c["H"], c["W"], 3)
+        if not c["ndc"]:
+            assert torch.equal(got[:, :3], ref[:, :3])                   # origins are copies of the translation
+        np.testing.assert_allclose(host(got), host(ref), atol=2e-7, rtol=2e-6)
+        assert torch.equal(got[:, 6:8], ref[:, 6:8])
+        # a row range equals the slice of the full matrix
+        part = ops.gen_rays(c["H"], c["W"], c["K"], c2w, c["near"], c["far"], c["vd"], c["ndc"], st, row0=2, nrows=3)
+        assert torch.equal(part, got[2 * c["W"]:5 * c["W"]])
+    # against the reference itself
+    g = ops.gen_rays(12, 12, gold["render_blender_K"], dev(gold["render_blender_c2w"]), 2., 6., True, False)
+    assert_bit_exact(host(g[:, :3]).reshape(12, 12, 3), gold["render_blender_rays_o"], "rays_o")
+    np.testing.assert_allclose(host(g[:, 3:6]).reshape(12, 12, 3), gold["render_blender_rays_d"], atol=1e-7, rtol=1e-6)
+    g = ops.gen_rays(9, 12, gold["render_ndc_K"], dev(gold["render_ndc_c2w"]), 0., 1., True, True)
+    np.testing.assert_allclose(host(g[:, :3]).reshape(9, 12, 3), gold["render_ndc_rays_o"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(host(g[:, 3:6]).reshape(9, 12, 3), gold["render_ndc_rays_d"], atol=1e-6, rtol=1e-5)
