@@ -37,7 +37,8 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
 
     coarse, fine = build_nets(torch, device)
     params = list(coarse.parameters()) + list(fine.parameters())
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    from nerf_amd.optim import FusedAdam
+    opt = FusedAdam(params, lr=5e-4, betas=(0.9, 0.999))   # what create_nerf hands out on the GPU
     e10, _ = get_embedder(10, 0)
     e4, _ = get_embedder(4, 0)
     kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=1., N_importance=128,

@@ -172,6 +172,14 @@ int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net_t *occ_net
                              int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
                              int32_t zero_canonical, float *raw, float *dx, void *stream);
 
+/* Fused optimizer step: torch.optim.Adam as model.py:52 / vanilla_dynamic/model.py:115 configure it
+ * (no weight decay, no amsgrad), all tensors in one launch.  The pointer tables and `numel` are HOST arrays of
+ * n_tensors entries holding DEVICE pointers; steps[i] is tensor i's 1-based step count (torch counts per parameter); grad_scale: NULL or a DEVICE scalar the
+ * gradients are multiplied by (the clip_grad_norm_ coefficient, vanilla_dynamic/train.py:273-274). */
+int nrf_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                  float *const *exp_avg_sq, const int64_t *numel, const int64_t *steps, float lr, float beta1, float beta2,
+                  float eps, const float *grad_scale, void *stream);
+
 /* K4  raw2outputs -- render.py:82-131.  raw [N,S,4], z_vals [N,S], rays_d rows of `d_stride` floats
  * (pass rays+3 with d_stride = ncol to read directions out of the ray matrix), noise NULL or [N,S]
  * (already multiplied by raw_noise_std).  Outputs rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]. */

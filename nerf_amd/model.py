@@ -7,6 +7,8 @@ import os
 
 import torch
 
+from .optim import make_adam
+
 from .network import NeRF
 from .positional_encoding import get_embedder
 from .render import run_network
@@ -37,7 +39,7 @@ def create_nerf(args):
         return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
                            netchunk=args.netchunk)
 
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    optimizer = make_adam(grad_vars, lr=args.lrate, betas=(0.9, 0.999))   # model.py:52, one launch per step on the GPU
 
     # checkpoint discovery: explicit --ft_path, else the newest *.tar under basedir/expname (model.py:59-81)
     start = 0

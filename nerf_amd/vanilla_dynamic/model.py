@@ -3,8 +3,8 @@ Same argument names, same render_kwargs dictionaries, same checkpoint keys."""
 import os
 
 import torch
-import torch.optim as optim
 
+from ..optim import make_adam
 from .network import DNeRF_Deformation, DNeRF_Straightforward
 from .positional_encoding import get_embedder, get_time_embedder
 from .render import run_network_dnerf
@@ -56,7 +56,7 @@ def create_dnerf(args):
                                  embed_time_fn=embed_time_fn, netchunk=args.netchunk,
                                  network_type=args.network_type)
 
-    optimizer = optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    optimizer = make_adam(grad_vars, lr=args.lrate, betas=(0.9, 0.999))   # vanilla_dynamic/model.py:115
 
     start = 0
     if args.ft_path is not None and args.ft_path != 'None':
