@@ -282,6 +282,37 @@ def gen_static(out):
     print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
 
 
+def gen_static_pytest(out):
+    """The reference's fixed-random route (pytest=True, render.py:113-117, :203-206; sampling.py:37-45): stratified
+    jitter, uniform density noise and random resampling, all from numpy seeded with 0 -- a deterministic end-to-end
+    vector for perturb=1 / raw_noise_std>0."""
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, REF)
+    import torch
+    import positional_encoding as pe
+    import network
+    import render as rr
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    T = torch.from_numpy
+    e10, _ = pe.get_embedder(10, 0)
+    e4, _ = pe.get_embedder(4, 0)
+    q = lambda inputs, viewdirs, fn: rr.run_network(inputs, viewdirs, fn, e10, e4, 65536)  # noqa: E731
+    c_s = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(24))
+    f_s = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(25))
+    rays = fx.blender_rays(64, 11)
+    G["rays"] = rays
+    with torch.no_grad():
+        for name, kw in (("jitter_noise", dict(perturb=1., raw_noise_std=1.)), ("jitter", dict(perturb=1., raw_noise_std=0.)),
+                         ("noise", dict(perturb=0., raw_noise_std=0.5))):
+            ret = rr.render_rays(T(rays), c_s, q, 64, retraw=True, N_importance=128, network_fine=f_s, white_bkgd=True,
+                                 pytest=True, **kw)
+            for k, v in ret.items():
+                G[f"{name}_{k}"] = v.numpy()
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
 def gen_dnerf(out):
     sys.modules["imageio"] = types.ModuleType("imageio")
     sys.path.insert(0, os.path.join(REF, "vanilla_dynamic"))
@@ -380,4 +411,4 @@ def gen_dnerf(out):
 
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"static": gen_static, "dnerf": gen_dnerf}[which](os.path.join(HERE, f"{which}.npz"))
+    {"static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest}[which](os.path.join(HERE, f"{which}.npz"))

@@ -246,3 +246,26 @@ def test_fused_ray_matrix(gold):
     g = ops.gen_rays(9, 12, gold["render_ndc_K"], dev(gold["render_ndc_c2w"]), 0., 1., True, True)
     np.testing.assert_allclose(host(g[:, :3]).reshape(9, 12, 3), gold["render_ndc_rays_o"], atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(host(g[:, 3:6]).reshape(9, 12, 3), gold["render_ndc_rays_d"], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,kw", [("jitter_noise", dict(perturb=1., raw_noise_std=1.)),
+                                     ("jitter", dict(perturb=1., raw_noise_std=0.)),
+                                     ("noise", dict(perturb=0., raw_noise_std=0.5))])
+def test_fixed_random_route_vs_reference(query_fn, name, kw):
+    """pytest=True (render.py:113-117, :203-206; sampling.py:37-45): stratified jitter, uniform density noise and random
+    resampling drawn from numpy seeded with 0 -- the reference's own deterministic test mode, end to end on the
+    well-conditioned nets (tests/golden/static_pytest.npz, generated by the imported reference)."""
+    import os
+    from nerf_amd.render import render_rays
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "static_pytest.npz"))
+    coarse, fine = load_net(fx.make_nerf_state(24)), load_net(fx.make_nerf_state(25))
+    with torch.no_grad():
+        ret = render_rays(dev(G["rays"]), coarse, query_fn, 64, retraw=True, N_importance=128, network_fine=fine,
+                          white_bkgd=True, pytest=True, **kw)
+    for k in ("rgb0", "acc0", "rgb_map", "acc_map", "z_std"):
+        np.testing.assert_allclose(host(ret[k]), G[f"{name}_{k}"], atol=1e-4, rtol=0, err_msg=f"{name} {k}")
+    np.testing.assert_allclose(host(ret["disp_map"]), G[f"{name}_disp_map"], atol=1e-4, rtol=1e-3, err_msg=name)
+    # the fine net's raw outputs sit at resampled positions: a 1e-7 difference in a coarse weight moves a few of the
+    # 128 random draws by a bin (the discontinuity discussed in conftest.assert_mostly_close); the rendered values
+    # above are insensitive to it
+    assert_mostly_close(host(ret["raw"]), G[f"{name}_raw"], atol=1e-4, frac=0.99, hard=5e-2, what=f"{name} raw")
