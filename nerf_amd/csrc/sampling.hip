@@ -324,6 +324,72 @@ extern "C" int nrf_gen_rays(int32_t H, int32_t W, float fx, float fy, float cx, 
     return nrf::check_launch("nrf_gen_rays");
 }
 
+// K0b: rows of train.py's shuffled rays_rgb table (train.py:147-153, batches :183-185) without the
+// table: row r of the unshuffled table is (train image r / (H*W), pixel r % (H*W)); its ray comes from get_rays_np
+// (rays.py:43-48) and its target from the image.  `f64`: the arithmetic the reference's numpy performs -- a float64
+// intrinsics matrix promotes get_rays_np to float64 under NumPy >= 2, rounded once by .astype(float32) (1); NumPy 1.x
+// keeps float32 (0, the operation order of get_rays).
+struct RayBatchArgs {
+    const int64_t *rows;
+    const int32_t *img_index;        // table slot -> image / pose index (i_train); null = identity
+    const float *poses, *images;     // poses: 3 rows of >= 4 floats per image; images [*, H, W, 3]
+    int64_t n, pose_pitch;
+    int32_t pose_stride, H, W, n_slots, f64;
+    double fx, fy, cx, cy;
+    float *rays, *rgb;               // [2, n, 3], [n, 3]
+};
+
+__global__ void __launch_bounds__(256) ray_batch_kernel(const RayBatchArgs a) {
+    const int64_t hw = (int64_t)a.H * a.W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = a.rows[e];
+        float *ro = a.rays + e * 3, *rd = a.rays + (a.n + e) * 3, *c = a.rgb + e * 3;
+        if (r < 0 || r >= hw * a.n_slots) {   // a row outside the table: make it visible instead of reading out of bounds
+            const float q = __builtin_nanf("");
+            for (int k = 0; k < 3; ++k) { ro[k] = q; rd[k] = q; c[k] = q; }
+            continue;
+        }
+        const int slot = (int)(r / hw);
+        const int64_t pix = r - slot * hw;
+        const int img = a.img_index ? a.img_index[slot] : slot;
+        const float col = (float)(pix % a.W), row = (float)(pix / a.W);
+        const float *m = a.poses + img * a.pose_pitch;
+        if (a.f64) {
+            const double x = ((double)col - a.cx) / a.fx, y = -((double)row - a.cy) / a.fy;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float *q = m + k * a.pose_stride;
+                rd[k] = (float)(__dadd_rn(__dadd_rn(__dmul_rn(x, (double)q[0]), __dmul_rn(y, (double)q[1])),
+                                          __dmul_rn(-1.0, (double)q[2])));
+                ro[k] = q[3];
+            }
+        } else {
+            float o[3], d[3];
+            pose_ray(m, a.pose_stride, __fdiv_rn(__fsub_rn(col, (float)a.cx), (float)a.fx),
+                     __fdiv_rn(-__fsub_rn(row, (float)a.cy), (float)a.fy), o, d);
+            for (int k = 0; k < 3; ++k) { ro[k] = o[k]; rd[k] = d[k]; }
+        }
+        const float *px = a.images + ((int64_t)img * hw + pix) * 3;
+        c[0] = px[0]; c[1] = px[1]; c[2] = px[2];
+    }
+}
+
+extern "C" int nrf_gather_ray_batch(const int64_t *rows, int64_t n, const int32_t *img_index, int32_t n_slots,
+                                    const float *poses, int32_t pose_stride, int64_t pose_pitch, const float *images,
+                                    int32_t H, int32_t W, double fx, double fy, double cx, double cy, int32_t f64,
+                                    float *rays, float *rgb, void *stream) {
+    NRF_REQUIRE(H >= 1 && W >= 1 && n >= 0 && n_slots >= 1, "nrf_gather_ray_batch: bad image / table size");
+    NRF_REQUIRE(pose_stride >= 4 && pose_pitch >= 2 * (int64_t)pose_stride + 4, "nrf_gather_ray_batch: pose layout");
+    if (n == 0) return NRF_OK;
+    NRF_REQUIRE(rows && poses && images && rays && rgb, "nrf_gather_ray_batch: null pointer");
+    RayBatchArgs a{};
+    a.rows = rows; a.img_index = img_index; a.poses = poses; a.images = images; a.n = n; a.pose_pitch = pose_pitch;
+    a.pose_stride = pose_stride; a.H = H; a.W = W; a.n_slots = n_slots; a.f64 = f64;
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.rays = rays; a.rgb = rgb;
+    hipLaunchKernelGGL(ray_batch_kernel, dim3(nrf::grid_for(n, 256)), dim3(256), 0, nrf::as_stream(stream), a);
+    return nrf::check_launch("nrf_gather_ray_batch");
+}
+
 extern "C" int nrf_sample_coarse(const float *rays, int64_t n_rays, int32_t ncol, int32_t n_samples,
                                  int32_t lindisp, const float *t_rand, float *z_vals, void *stream) {
     if (n_rays != 0) NRF_REQUIRE(rays && z_vals, "nrf_sample_coarse: null pointer");

@@ -51,6 +51,35 @@ def gen_rays(H, W, K, c2w, near, far, use_viewdirs, ndc, c2w_staticcam=None, row
     return rays
 
 
+def gather_ray_batch(rows, images, poses, H, W, K, img_index=None, f64=True):
+    """Rows of train.py:147-153's UNSHUFFLED rays_rgb table -> (batch_rays [2, n, 3], target_s [n, 3]), computed from
+    (images [M, H, W, 3], poses [M, >=3, >=4]) on the fly.  rows: int64 device tensor; img_index: int32 device tensor
+    mapping table slots to images (i_train)."""
+    images = _f32(images, "images")
+    poses = _f32(poses, "poses")
+    if rows.dtype != torch.int64 or not rows.is_cuda:
+        raise RuntimeError("rows: expected an int64 GPU tensor")
+    rows = rows.contiguous()
+    if images.dim() != 4 or images.shape[1] != H or images.shape[2] != W or images.shape[3] != 3:
+        raise ValueError(f"images: expected [M, {H}, {W}, 3], got {tuple(images.shape)}")
+    if poses.dim() != 3 or poses.shape[1] < 3 or poses.shape[2] < 4 or poses.shape[0] != images.shape[0]:
+        raise ValueError(f"poses: expected [{images.shape[0]}, >=3, >=4], got {tuple(poses.shape)}")
+    n_slots = images.shape[0]
+    if img_index is not None:
+        if img_index.dtype != torch.int32 or not img_index.is_cuda:
+            raise RuntimeError("img_index: expected an int32 GPU tensor")
+        img_index = img_index.contiguous()
+        n_slots = img_index.numel()
+    n = rows.numel()
+    rays = torch.empty((2, n, 3), device=images.device, dtype=torch.float32)
+    rgb = torch.empty((n, 3), device=images.device, dtype=torch.float32)
+    check(_lib.lib().nrf_gather_ray_batch(_ptr(rows), n, _ptr(img_index), int(n_slots), _ptr(poses), int(poses.stride(1)),
+                                          int(poses.stride(0)), _ptr(images), int(H), int(W), float(K[0][0]),
+                                          float(K[1][1]), float(K[0][2]), float(K[1][2]), int(bool(f64)), _ptr(rays),
+                                          _ptr(rgb), _stream()), "nrf_gather_ray_batch")
+    return rays, rgb
+
+
 # ---------------------------------------------------------------- sampling
 def sample_coarse(rays, n_samples, lindisp=False, t_rand=None):
     """render.py:186-208 -> z_vals [N, S]."""

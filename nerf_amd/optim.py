@@ -62,6 +62,9 @@ class FusedAdam:
             self._table([self.exp_avg[i] for i in idx]), self._table([self.exp_avg_sq[i] for i in idx]), numel,
             steps, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
             C.c_void_p(scale.data_ptr()) if scale is not None else None, _stream()), "nrf_adam_step")
+        # the kernel wrote through raw pointers: tell autograd (and the packed-weight caches keyed on `_version`,
+        # ops.PackedNet.refresh) that these tensors changed
+        torch.autograd.graph.increment_version([self.params[i] for i in idx])
         return total_norm
 
     # ---- torch.optim.Adam-compatible (de)serialisation

@@ -3,6 +3,7 @@
 
     python tests/golden/make_golden.py static     -> tests/golden/static.npz
     python tests/golden/make_golden.py dnerf      -> tests/golden/dnerf.npz
+    python tests/golden/make_golden.py tooling    -> tests/golden/tooling.npz + tests/golden/ref_ckpt_small.tar
 
 The reference (a pure-Python/PyTorch project at /root/reference) cannot travel to the GPU box, so
 its outputs on seeded synthetic inputs are frozen here as data.  Inputs come from
@@ -409,6 +410,65 @@ def gen_dnerf(out):
     print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
 
 
+def gen_tooling(out):
+    """(1) the rays_rgb table of train.py:147-153 built with the reference's get_rays_np; (2) a checkpoint in
+    the on-disk format of train.py:260-265 written from the reference's NeRF modules + torch Adam, with the networks'
+    outputs before and after one more optimizer step."""
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, REF)
+    import torch
+    import network
+    import rays as rays_mod
+    G = {"meta": _meta(torch), "numpy": np.array([np.__version__])}
+    rng = np.random.RandomState(77)
+
+    # ---- (1) train.py:147-153, restated call for call on a small scene
+    H, W, focal = 5, 7, 6.5
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])           # train.py builds K like this (float64)
+    poses = np.stack([fx.pose_spherical(t, -30.0, 4.0) for t in (-120.0, -10.0, 45.0, 160.0)]).astype(np.float32)
+    images = rng.rand(4, H, W, 3).astype(np.float32)
+    i_train = np.array([0, 2, 3])
+    rays = np.stack([rays_mod.get_rays_np(H, W, K, p) for p in poses[:, :3, :4]], 0)
+    rays_rgb = np.concatenate([rays, images[:, None]], 1)
+    rays_rgb = np.transpose(rays_rgb, [0, 2, 3, 1, 4])
+    rays_rgb = np.stack([rays_rgb[i] for i in i_train], 0)
+    rays_rgb = np.reshape(rays_rgb, [-1, 3, 3])
+    G["table_dtype_before_cast"] = np.array([str(rays_rgb.dtype)])
+    rays_rgb = rays_rgb.astype(np.float32)
+    G.update(table=rays_rgb, table_K=K, table_poses=poses, table_images=images, table_i_train=i_train,
+             table_hw=np.array([H, W]))
+
+    # ---- (2) checkpoint
+    torch.manual_seed(5)
+    mk = lambda: network.NeRF(D=3, W=128, input_ch=63, output_ch=5, skips=[1], input_ch_views=27, use_viewdirs=True)  # noqa: E731
+    coarse, fine = mk(), mk()
+    grad_vars = list(coarse.parameters()) + list(fine.parameters())
+    opt = torch.optim.Adam(params=grad_vars, lr=5e-4, betas=(0.9, 0.999))          # model.py:52
+    x = torch.from_numpy(rng.uniform(-1, 1, (96, 90)).astype(np.float32))
+    tgt = torch.from_numpy(rng.uniform(0, 1, (96, 4)).astype(np.float32))
+
+    def step():
+        opt.zero_grad()
+        loss = ((coarse(x) - tgt) ** 2).mean() + ((fine(x) - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    step(); step()
+    path = os.path.join(HERE, "ref_ckpt_small.tar")
+    torch.save({'global_step': 2, 'network_fn_state_dict': coarse.state_dict(),
+                'network_fine_state_dict': fine.state_dict(), 'optimizer_state_dict': opt.state_dict()}, path)
+    with torch.no_grad():
+        G["ckpt_out_coarse"], G["ckpt_out_fine"] = coarse(x).numpy(), fine(x).numpy()
+    G["ckpt_loss3"] = np.array([step()])
+    with torch.no_grad():
+        G["ckpt_out3_coarse"], G["ckpt_out3_fine"] = coarse(x).numpy(), fine(x).numpy()
+    G.update(ckpt_x=x.numpy(), ckpt_tgt=tgt.numpy())
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), "and", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest}[which](os.path.join(HERE, f"{which}.npz"))
+    {"static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest,
+     "tooling": gen_tooling}[which](os.path.join(HERE, f"{which}.npz"))

@@ -61,3 +61,23 @@ def test_state_dict_round_trip_with_torch():
     opt2.step()
     for pa, pb in zip(a, b):
         np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_step_invalidates_packed_weights():
+    """The fused step writes parameters through raw pointers; the networks' packed copies must notice."""
+    from nerf_amd.network import NeRF
+    from nerf_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True).cuda()
+    opt = FusedAdam(list(net.parameters()), lr=1e-2)
+    x = torch.rand(256, 90, device="cuda") * 2 - 1
+    before = [p._version for p in net.parameters()]
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = (net(x) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(p._version > v for p, v in zip(net.parameters(), before))
+    assert losses[1] != losses[0] and losses[-1] < losses[0]

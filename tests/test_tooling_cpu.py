@@ -1,0 +1,71 @@
+"""Checkpoint tooling on the host: the reference-format checkpoint written by the imported reference
+(tests/golden/make_golden.py tooling) is read with the safe loader and its architecture recovered from shapes."""
+import os
+
+import numpy as np
+import torch
+
+import nerf_fixtures as fx
+from nerf_amd import checkpoint as ck
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CKPT = os.path.join(GOLD, "ref_ckpt_small.tar")
+
+
+def test_reference_checkpoint_architecture():
+    c = ck.read_checkpoint(CKPT)
+    assert c["global_step"] == 2
+    for key in ("network_fn_state_dict", "network_fine_state_dict"):
+        a = ck.infer_nerf_arch(c[key])
+        assert a == dict(D=3, W=128, input_ch=63, input_ch_views=27, output_ch=4, skips=[1], use_viewdirs=True)
+    assert len(c["optimizer_state_dict"]["state"]) == 28
+    text = ck.describe(CKPT)
+    assert "global_step 2" in text and "76100 parameters" in text
+
+
+def test_infer_default_architectures():
+    sd = {k: torch.from_numpy(v) for k, v in fx.make_nerf_state(0).items()}
+    assert ck.infer_nerf_arch(sd) == dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4],
+                                          use_viewdirs=True)
+    sd = {k: torch.from_numpy(v) for k, v in fx.make_nerf_state(0, input_ch_views=0, output_ch=5,
+                                                                use_viewdirs=False).items()}
+    a = ck.infer_nerf_arch(sd)
+    assert (a["use_viewdirs"], a["output_ch"], a["input_ch_views"]) == (False, 5, 0)
+    sd = {k: torch.from_numpy(v) for k, v in fx.make_dnerf_state(0).items()}
+    assert ck.is_dnerf(sd)
+    a = ck.infer_dnerf_arch(sd)
+    assert (a["D"], a["W"], a["D_deform"], a["W_deform"]) == (8, 256, 8, 256)
+    assert (a["input_ch"], a["input_ch_views"], a["input_ch_time"]) == (63, 27, 21)
+    assert a["skips"] == [4] and a["skips_deform"] == [4] and a["use_viewdirs"] and not a["use_layernorm"]
+
+
+def test_multires_from_channels():
+    assert ck._multires(63) == 10 and ck._multires(27) == 4 and ck._multires(21, dims=1) == 10
+    try:
+        ck._multires(64)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("64 channels is not a default embedding width")
+
+
+def test_save_is_the_reference_layout(tmp_path):
+    from nerf_amd.network import NeRF
+    m = NeRF(D=3, W=128, input_ch=63, input_ch_views=27, output_ch=5, skips=[1], use_viewdirs=True)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    p = str(tmp_path / "000002.tar")
+    ck.save_checkpoint(p, 2, m, None, opt)
+    ref = ck.read_checkpoint(CKPT)
+    mine = ck.read_checkpoint(p)
+    assert list(mine["network_fn_state_dict"]) == list(ref["network_fn_state_dict"])
+    assert "network_fine_state_dict" not in mine and set(mine) <= set(ref)
+    for k, v in ref["network_fn_state_dict"].items():
+        assert mine["network_fn_state_dict"][k].shape == v.shape
+
+
+def test_ray_table_golden_is_float64_rounded_once():
+    g = np.load(os.path.join(GOLD, "tooling.npz"))
+    # NumPy >= 2 promotes get_rays_np to float64 for train.py's float64 K; the table is cast afterwards (train.py:153)
+    assert str(g["table_dtype_before_cast"][0]) == "float64"
+    H, W = g["table_hw"]
+    assert g["table"].shape == (3 * H * W, 3, 3) and g["table"].dtype == np.float32
