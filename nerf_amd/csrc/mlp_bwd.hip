@@ -293,8 +293,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
             }
         }
     };
-    f32x4 A[4], B[4];
-    auto read_frags = [&](int stage) {
+    // Fragments are double-buffered in registers: step s+1's are read from LDS under step s's MFMAs, so the matrix
+    // pipe restarts right after the barrier instead of waiting out the LDS latency.
+    f32x4 A0[4], B0[4], A1[4], B1[4];
+    auto read_frags = [&](f32x4 (&A)[4], f32x4 (&B)[4], int stage) {
         const char *base = lds + stage * kWgStage + lane * 16;
 #pragma unroll
         for (int x = 0; x < 4; ++x)
@@ -303,19 +305,19 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
         for (int y = 0; y < 4; ++y)
             if (y < ka) B[y] = *reinterpret_cast<const f32x4 *>(base + (8 + (wib & 1) * 4 + y) * 1024);
     };
-
-    if (nsteps > 0) request(0, 0);
-    if (nsteps > 1) request(1, 1);
-    int st_cur = 0, st_req = 2;
-    for (int64_t step = 0; step < nsteps; ++step) {
-        // own copies of step+1 (and older) have landed; after the barrier everyone's have, and everyone has finished
-        // reading step-1's stage, which the request for step+2 reuses
+    auto land = [&]() {   // own copies have landed; after the barrier everyone's have
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    int st_nxt = 1, st_req = 2;
+    // iteration `step`: stage(step+1) has landed for everyone (its fragments are read now, for the next iteration);
+    // stage(step-1) == stage(step+2) was last read during iteration step-2, so the request for step+2 may overwrite it
+    auto body = [&](int64_t step, f32x4 (&A)[4], f32x4 (&B)[4], f32x4 (&An)[4], f32x4 (&Bn)[4]) {
+        land();
         if (step + 2 < nsteps) request(step + 2, st_req);
         if (active) {
-            read_frags(st_cur);
+            if (step + 1 < nsteps) read_frags(An, Bn, st_nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int x = 0; x < 4; ++x)
@@ -331,8 +333,19 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        st_cur = st_cur == 2 ? 0 : st_cur + 1;
+        st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
         st_req = st_req == 2 ? 0 : st_req + 1;
+    };
+
+    if (nsteps > 0) {
+        request(0, 0);
+        request(1, 1);          // nsteps is a multiple of 4
+        land();
+        if (active) read_frags(A0, B0, 0);
+    }
+    for (int64_t step = 0; step < nsteps; step += 2) {
+        body(step, A0, B0, A1, B1);
+        body(step + 1, A1, B1, A0, B0);
     }
     if (!active) return;
     float *slab = a.slab + (int64_t)chunk * NP * KP;

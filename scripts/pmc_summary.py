@@ -19,6 +19,7 @@ def short(name):
 
 def main(root):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    dur = defaultdict(dict)     # kernel -> dispatch id -> ns (when the CSV carries timestamps)
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -27,9 +28,14 @@ def main(root):
                 a = acc[k][c]
                 a[0] += 1
                 a[1] += float(row.get("Counter_Value", 0) or 0)
+                if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                    dur[k][row.get("Dispatch_Id", len(dur[k]))] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
     out = {}
     for k, cs in acc.items():
         out[k] = {c: {"launches": n, "sum": s, "per_launch": s / max(n, 1)} for c, (n, s) in cs.items()}
+        if dur[k]:
+            out[k]["_duration_ns"] = {"launches": len(dur[k]), "sum": sum(dur[k].values()),
+                                      "per_launch": sum(dur[k].values()) / len(dur[k])}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 

@@ -17,6 +17,9 @@ for what in "$@"; do
     stats)
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render" -o render -- python3 $RENDER > "$OUT/render_stats.log" 2>&1
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN > "$OUT/train_stats.log" 2>&1 ;;
+    stats_train)
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN --no-cpu-baseline --no-extras > "$OUT/train_stats.log" 2>&1
+      head -6 "$OUT"/stats_train/train_kernel_stats.csv | cut -c1-150 ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
         timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_$c" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_render_$c.log" 2>&1
