@@ -11,6 +11,8 @@
 //     Bias gradients are the row sums of the same A operand.
 //  3. reduce + unpack: sums the slabs over chunks (fixed order: deterministic) and scatters into the
 //     nn.Linear [out, in] gradient layout, undoing the k-space permutation of the input blocks.
+#include <type_traits>
+
 #include "mlp_device.h"
 
 namespace nrf {
@@ -221,8 +223,8 @@ __global__ void __launch_bounds__(256) pe3_bwd_t8_kernel(const float *gbuf, int6
 // ------------------------------------------------------------------------------------------------
 // wgrad: slab[chunk][n][k] = sum_{points in chunk} G[n][p] * X[k][p]
 //
-// A workgroup owns a super-block of up to 8 x 8 channel tiles (256 x 256 of dW); wave (wy, wx) accumulates its
-// 4 x 4 tiles (256 accumulator registers).  Per step (8 points of one 32-point tile) the operands are the
+// A workgroup owns a super-block of up to 8 x 8 channel tiles (256 x 256 of dW); each wave accumulates a rectangle
+// of up to 4 x 4 tiles (256 accumulator registers).  Per step (8 points of one 32-point tile) the operands are the
 // super-block's <= 8 G pieces and <= 8 X pieces of 1 KiB; the four waves copy them global -> LDS ONCE
 // (buffer_load ... lds, a 3-stage ring, one barrier per step) and every wave reads its 4 + 4 fragments from LDS.
 // Without the sharing each wave pulled its own 8 KiB per 64 MFMAs = 8 B/clk/CU, the per-CU load limit (measured 60 %
@@ -242,6 +244,63 @@ struct WgradArgs {
 
 constexpr int kWgStage = 16384;
 
+// The step loop of wgrad_kernel for a wave that owns NA x KA tiles (0 x 0: a wave with no tiles still copies its share
+// of the pieces and takes part in the barriers).  Fragments are double-buffered in registers: step s+1's are read from
+// LDS under step s's MFMAs, so the matrix pipe restarts right after the barrier instead of waiting out the LDS latency.
+// Iteration `step`: stage(step+1) has landed for everyone (its fragments are read now, for the next iteration);
+// stage(step-1) == stage(step+2) was last read during iteration step-2, so the request for step+2 may overwrite it.
+// (Measured and dropped: copies three steps ahead with a partial vmcnt wait -- 6 % slower on full super-blocks, a
+// gain only on the few-tile ones, 0.4 % of the step overall.)
+template <int NA, int KA, class Req>
+__device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
+                                            int64_t nsteps, Req &&request) {
+    constexpr int NAr = NA ? NA : 1, KAr = KA ? KA : 1;
+    f32x4 A0[NAr], B0[KAr], A1[NAr], B1[KAr];
+    auto read_frags = [&](f32x4 (&A)[NAr], f32x4 (&B)[KAr], int stage) {
+        const char *base = lds + stage * kWgStage + lane * 16;
+#pragma unroll
+        for (int x = 0; x < NA; ++x) A[x] = *reinterpret_cast<const f32x4 *>(base + (nt0 + x) * 1024);
+#pragma unroll
+        for (int y = 0; y < KA; ++y) B[y] = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
+    };
+    auto land = [&]() {   // own copies have landed; after the barrier everyone's have
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int st_nxt = 1, st_req = 2;
+    auto body = [&](int64_t step, f32x4 (&A)[NAr], f32x4 (&B)[KAr], f32x4 (&An)[NAr], f32x4 (&Bn)[KAr]) {
+        land();
+        if (step + 2 < nsteps) request(step + 2, st_req);   // first: its latency is the step's critical path
+        if constexpr (NA > 0 && KA > 0) {
+            read_frags(An, Bn, st_nxt);     // past the last step this re-reads a stale stage: unused
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+                bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
+#pragma unroll
+                for (int y = 0; y < KA; ++y)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
+        st_req = st_req == 2 ? 0 : st_req + 1;
+    };
+    if (nsteps > 0) {
+        request(0, 0);
+        request(1, 1);          // nsteps is a multiple of 4
+        land();
+        if constexpr (NA > 0 && KA > 0) read_frags(A0, B0, 0);
+    }
+    for (int64_t step = 0; step < nsteps; step += 2) {
+        body(step, A0, B0, A1, B1);
+        body(step + 1, A1, B1, A0, B0);
+    }
+}
+
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
     const int lane = threadIdx.x & 63;
@@ -250,8 +309,19 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
     const int k_sblks = (a.k_tiles + 7) >> 3;
     const int nsb = blockIdx.y / k_sblks, ksb = blockIdx.y - nsb * k_sblks;
     const int gn = min(8, a.n_tiles - nsb * 8), xn = min(8, a.k_tiles - ksb * 8);   // pieces of the super-block
-    const int n0 = nsb * 8 + (wib >> 1) * 4, k0 = ksb * 8 + (wib & 1) * 4;
-    const int na = max(0, min(4, a.n_tiles - n0)), ka = max(0, min(4, a.k_tiles - k0));
+    // the super-block's gn x xn tiles are split over the four waves as a WY x WX grid of rectangles of <= 4 x 4
+    // tiles; the grid (2x2, 1x4 or 4x1) with the fewest tiles per wave wins, so skinny GEMMs (layer 0, the skip and
+    // view slices, the one-tile heads) keep all four matrix pipes busy
+    int WY = 2, best = 1 << 30;
+    for (int c = 0; c < 3; ++c) {
+        const int wy_c = c == 0 ? 2 : (c == 1 ? 1 : 4), wx_c = 4 / wy_c;
+        const int np = (gn + wy_c - 1) / wy_c, kp = (xn + wx_c - 1) / wx_c;
+        if (np <= 4 && kp <= 4 && np * kp < best) { best = np * kp; WY = wy_c; }
+    }
+    const int WX = 4 / WY, nper = (gn + WY - 1) / WY, kper = (xn + WX - 1) / WX;
+    const int nt0 = (wib / WX) * nper, kt0 = (wib % WX) * kper;   // this wave's first tile within the super-block
+    const int n0 = nsb * 8 + nt0, k0 = ksb * 8 + kt0;
+    const int na = max(0, min(nper, gn - nt0)), ka = max(0, min(kper, xn - kt0));
     const bool active = na > 0 && ka > 0;
     const int NP = a.n_tiles * 32, KP = a.k_tiles * 32;
     const int lane_src = ((lane & 31) * 8 + (lane >> 5) * 4) * 4;  // bytes in a piece: channel lane&31, points 4s..4s+3
@@ -293,59 +363,29 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
             }
         }
     };
-    // Fragments are double-buffered in registers: step s+1's are read from LDS under step s's MFMAs, so the matrix
-    // pipe restarts right after the barrier instead of waiting out the LDS latency.
-    f32x4 A0[4], B0[4], A1[4], B1[4];
-    auto read_frags = [&](f32x4 (&A)[4], f32x4 (&B)[4], int stage) {
-        const char *base = lds + stage * kWgStage + lane * 16;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (x < na) A[x] = *reinterpret_cast<const f32x4 *>(base + ((wib >> 1) * 4 + x) * 1024);
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-            if (y < ka) B[y] = *reinterpret_cast<const f32x4 *>(base + (8 + (wib & 1) * 4 + y) * 1024);
+    // The step loop is compiled once per tile rectangle (NA x KA known at compile time -> straight-line bodies with
+    // exact wait counts); waves of one workgroup may run different instances, all with the same barrier sequence.
+    auto run = [&](auto na_c, auto ka_c) {
+        constexpr int NA = decltype(na_c)::value, KA = decltype(ka_c)::value;
+        wgrad_steps<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
     };
-    auto land = [&]() {   // own copies have landed; after the barrier everyone's have
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    int st_nxt = 1, st_req = 2;
-    // iteration `step`: stage(step+1) has landed for everyone (its fragments are read now, for the next iteration);
-    // stage(step-1) == stage(step+2) was last read during iteration step-2, so the request for step+2 may overwrite it
-    auto body = [&](int64_t step, f32x4 (&A)[4], f32x4 (&B)[4], f32x4 (&An)[4], f32x4 (&Bn)[4]) {
-        land();
-        if (step + 2 < nsteps) request(step + 2, st_req);
-        if (active) {
-            if (step + 1 < nsteps) read_frags(An, Bn, st_nxt);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-                if (x < na) {
-                    bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
-#pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        if (y < ka) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
-                        }
-                }
-            __builtin_amdgcn_sched_barrier(0);
+    auto pick_k = [&](auto na_c) {
+        switch (ka) {
+            case 1: run(na_c, std::integral_constant<int, 1>{}); break;
+            case 2: run(na_c, std::integral_constant<int, 2>{}); break;
+            case 3: run(na_c, std::integral_constant<int, 3>{}); break;
+            default: run(na_c, std::integral_constant<int, 4>{}); break;
         }
-        st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
-        st_req = st_req == 2 ? 0 : st_req + 1;
     };
-
-    if (nsteps > 0) {
-        request(0, 0);
-        request(1, 1);          // nsteps is a multiple of 4
-        land();
-        if (active) read_frags(A0, B0, 0);
-    }
-    for (int64_t step = 0; step < nsteps; step += 2) {
-        body(step, A0, B0, A1, B1);
-        body(step + 1, A1, B1, A0, B0);
+    if (!active) {
+        wgrad_steps<0, 0>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+    } else {
+        switch (na) {
+            case 1: pick_k(std::integral_constant<int, 1>{}); break;
+            case 2: pick_k(std::integral_constant<int, 2>{}); break;
+            case 3: pick_k(std::integral_constant<int, 3>{}); break;
+            default: pick_k(std::integral_constant<int, 4>{}); break;
+        }
     }
     if (!active) return;
     float *slab = a.slab + (int64_t)chunk * NP * KP;
