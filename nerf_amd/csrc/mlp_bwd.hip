@@ -40,6 +40,19 @@ __device__ __forceinline__ void store_acc_t8c(const TBuf &tb, uint32_t sec, int 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// group G's share of store_acc_t8c (registers 4(G&3)..+3 of tile G>>2), issued under the GEMM that consumes v
+template <int NT>
+__device__ __forceinline__ void store_acc_t8c_group(const TBuf &tb, uint32_t sec, int voff, const f32x16 (&v)[NT], int G) {
+    const int t = G >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * (G & 3) + i;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), tb.rsrc, voff,
+                                              (int)((sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0);
+    }
+}
+__device__ __forceinline__ int t8c_voff(const TBuf &tb, int C) { return ((tb.m * C + 4 * tb.h) * 8 + tb.q7) * 4; }
+
 // head tile: 32 channels starting at channel c0 of a section with C channels; channel c0+o = vals[o] (o < n), else 0
 __device__ __forceinline__ void store_head_tile(const TBuf &tb, uint32_t sec, int C, int c0, const float (&vals)[8],
                                                 int n) {
@@ -153,15 +166,26 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
                 axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NT / 2) * 32, gr.y);
                 axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NT / 2) * 32, gr.z);
                 apply_gate_bits<NT / 2>(load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane), g2);
-                store_acc_t8c<NT / 2>(tg, (uint32_t)tl.g_hv, W / 2, g2);
+                // every gradient block is saved (for wgrad) by the GEMM that consumes it, four registers per k-group
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
-                gemm_hid<NT / 2, NT>(g, g2, wb, (uint32_t)pl.viewsT_w);
-                store_acc_t8c<NT>(tg, (uint32_t)tl.g_feat, W + 32, g);
+                {
+                    uint32_t sec = (uint32_t)tl.g_hv;
+                    asm volatile("" : "+s"(sec));
+                    const int voff = t8c_voff(tg, W / 2);
+                    gemm_hid_side<NT / 2, NT>(g, g2, wb, (uint32_t)pl.viewsT_w,
+                                              [&](int G) { store_acc_t8c_group<NT / 2>(tg, sec, voff, g2, G); });
+                }
                 float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);       // d/d(alpha): alpha_linear wgrad
                 // through feature_linear and alpha_linear (network.py:56-57) -> d/d(h_{D-1})
                 zero_acc<NT>(nx);
-                gemm_hid<NT, NT>(nx, g, wb, (uint32_t)pl.featT_w);
+                {
+                    uint32_t sec = (uint32_t)tl.g_feat;
+                    asm volatile("" : "+s"(sec));
+                    const int voff = t8c_voff(tg, W + 32);
+                    gemm_hid_side<NT, NT>(nx, g, wb, (uint32_t)pl.featT_w,
+                                          [&](int G) { store_acc_t8c_group<NT>(tg, sec, voff, g, G); });
+                }
                 axpy_head<NT>(nx, wb, (uint32_t)pl.alpha_vec, gr.w);
                 relu_move<NT>(g, nx, false);
             }
@@ -179,7 +203,6 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
         for (int l = pl.n_trunk - 1; l >= 0; --l) {
             apply_gate_bits<NT>(gate, g);
             if (l > 0) gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);   // in flight during this layer's GEMM
-            store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk + l * (32 * W), W, g);
             if constexpr (GX) {
                 if (l == 0 || ((pl.skip_in_mask >> l) & 1)) {   // g_x += W_l[:, :input_ch]^T g_l
                     --xi;
@@ -188,8 +211,14 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
             }
             if (l > 0) {
                 zero_acc<NT>(nx);
-                gemm_hid<NT, NT>(nx, g, wb, (uint32_t)(pl.trunkT_base + (int64_t)(l - 1) * pl.trunkT_stride));
+                uint32_t sec = (uint32_t)tl.g_trunk + l * (32 * W);
+                asm volatile("" : "+s"(sec));
+                const int voff = t8c_voff(tg, W);
+                gemm_hid_side<NT, NT>(nx, g, wb, (uint32_t)(pl.trunkT_base + (int64_t)(l - 1) * pl.trunkT_stride),
+                                      [&](int G) { store_acc_t8c_group<NT>(tg, sec, voff, g, G); });
                 relu_move<NT>(g, nx, false);
+            } else {
+                store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk, W, g);      // layer 0's block has no consumer
             }
         }
         if constexpr (GX) store_acc_t8c<2>(tg, (uint32_t)tl.g_xin, 64, gx);

@@ -263,6 +263,7 @@ __device__ __forceinline__ void load_wgroup(f32x4 (&wv)[NT_OUT], const WBuf &wb,
         f32x4(&cur)[NT_OUT] = (G & 1) ? wb_ : wa;                                                       \
         f32x4(&nxt)[NT_OUT] = (G & 1) ? wa : wb_;                                                       \
         if (G + 1 < (NG)) load_wgroup<NT_OUT>(nxt, wb, w, G + 1);                                       \
+        NRF_GEMM_SIDE(G) /* after the loads: the in-order vmcnt wait for them must not wait for side stores */ \
         __builtin_amdgcn_sched_barrier(0);                                                              \
         _Pragma("unroll") for (int t = 0; t < NT_OUT; ++t) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][i], SRC, acc[t], 0, 0, 0);             \
@@ -270,6 +271,7 @@ __device__ __forceinline__ void load_wgroup(f32x4 (&wv)[NT_OUT], const WBuf &wb,
     }
 
 // acc[t] += W_block * xin   (input block held as one register per k-step)
+#define NRF_GEMM_SIDE(G)
 template <int KS, int NT_OUT>
 __device__ __forceinline__ void gemm_in(f32x16 (&acc)[NT_OUT], const float (&xin)[KS], const WBuf &wb, uint32_t w) {
     NRF_GEMM_BODY(KS / 4, xin[4 * G + i])
@@ -281,6 +283,19 @@ __device__ __forceinline__ void gemm_hid(f32x16 (&acc)[NT_OUT], const f32x16 (&h
                                          uint32_t w) {
     NRF_GEMM_BODY(4 * NT_IN, hin[G >> 2][4 * (G & 3) + i])
 }
+#undef NRF_GEMM_SIDE
+
+// The same, with a side job per k-group: side(G) is issued under group G's MFMAs (G is a constant after
+// unrolling).  The training kernels save the operand they are consuming this way -- group G's four registers,
+// four stores -- instead of a burst of 16 * NT_IN stores between layers that backs up the store path while the
+// matrix pipe idles.
+#define NRF_GEMM_SIDE(G) side(G);
+template <int NT_IN, int NT_OUT, class Side>
+__device__ __forceinline__ void gemm_hid_side(f32x16 (&acc)[NT_OUT], const f32x16 (&hin)[NT_IN], const WBuf &wb,
+                                              uint32_t w, Side &&side) {
+    NRF_GEMM_BODY(4 * NT_IN, hin[G >> 2][4 * (G & 3) + i])
+}
+#undef NRF_GEMM_SIDE
 
 template <int NT>
 __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], bool relu) {
@@ -349,6 +364,36 @@ __device__ __forceinline__ void store_acc_t8(const TBuf &tb, uint32_t sec, const
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), tb.rsrc, voff,
                                                   (int)((sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0);
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// group G's share of store_acc_t8: registers 4(G&3) .. +3 of tile G>>2 (the ones group G's MFMAs read)
+template <int NT>
+__device__ __forceinline__ void store_acc_t8_group(const TBuf &tb, uint32_t sec, const f32x16 (&v)[NT], int G) {
+    constexpr int C = 32 * NT;
+    const int t = G >> 2;
+    const int voff = ((tb.m * C + 4 * tb.h) * 8 + tb.q7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * (G & 3) + i;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), tb.rsrc, voff,
+                                              (int)((sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0);
+    }
+}
+// group G's share of the gate bits (same bit order as store_gate_bits); the last group stores the four dwords
+template <int NT>
+__device__ __forceinline__ void gate_bits_group(const TBuf &tb, uint32_t slot, const f32x16 (&h)[NT], int lane,
+                                                uint32_t (&m)[4], int G) {
+    const int t = G >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = min(__float_as_uint(h[t][4 * (G & 3) + i]), 1u);
+        m[t >> 1] = (m[t >> 1] << 1) | b;
+    }
+    if (G == 4 * NT - 1) {
+        if constexpr (NT & 1) m[NT >> 1] <<= 16;
+        u32x4 v = {m[0], m[1], m[2], m[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, tb.rsrc, lane * 16, (int)(slot * 4), 0);
+    }
 }
 
 // ReLU gates of NT tiles as bits (the backward chain's only use of the trunk activations): tile t, register r ->

@@ -12,6 +12,8 @@
 //     dot products (VALU) finished with one cross-half shuffle;
 //   * sin/cos use the accurate range-reducing device functions (arguments reach ~3000 rad).
 // The kernel is MFMA-bound: 593 920 MAC per point issued (593 408 algorithmic, 99.9 %).
+#include <array>
+
 #include "mlp_device.h"
 
 namespace nrf {
@@ -72,32 +74,42 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             gemm_in<kKsT, NT>(acc, tin, wb, (uint32_t)pl.l0_w2);
         }
         relu_move<NT>(hin, acc, true);
-        if constexpr (TRAIN) {
-            store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk, hin);
-            store_gate_bits<NT>(tb, (uint32_t)a.tl.a_mask, hin, lane);
-        }
+        // TRAIN: a layer's activations (and their ReLU gate bits) are saved by the GEMM that consumes them, four
+        // registers per k-group under that group's MFMAs (save_hin); only a layer with no consumer saves in a burst
+        auto save_hin = [&](int l) {
+            uint32_t sec = (uint32_t)a.tl.a_trunk + l * (32 * 32 * NT), slot = (uint32_t)a.tl.a_mask + l * 256;
+            asm volatile("" : "+s"(sec), "+s"(slot));
+            return [&tb, &hin, sec, slot, lane, m = std::array<uint32_t, 4>{}](int G) mutable {
+                store_acc_t8_group<NT>(tb, sec, hin, G);
+                gate_bits_group<NT>(tb, slot, hin, lane, reinterpret_cast<uint32_t(&)[4]>(*m.data()), G);
+            };
+        };
         for (int l = 1; l < pl.n_trunk; ++l) {
             const uint32_t slot = (uint32_t)(pl.trunk_base + (int64_t)(l - 1) * pl.trunk_stride);
             load_bias<NT>(acc, wb, slot);
             if ((pl.skip_in_mask >> l) & 1) gemm_in<kKsX, NT>(acc, xin, wb, slot + skip_off);
-            gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
+            if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, slot + hid_off, save_hin(l - 1));
+            else gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
             relu_move<NT>(hin, acc, true);
-            if constexpr (TRAIN) {
-                store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk + l * (32 * 32 * NT), hin);
-                store_gate_bits<NT>(tb, (uint32_t)a.tl.a_mask + l * 256, hin, lane);
-            }
         }
         if (pl.use_viewdirs) {
             if constexpr (NT >= 2) {
                 const float alpha = head_dot<NT>(hin, wb, (uint32_t)pl.alpha_vec) + wload1(wb, (uint32_t)pl.alpha_b * 4);
                 load_bias<NT>(acc, wb, (uint32_t)pl.feat_b);                                     // network.py:57
-                gemm_hid<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w);
+                if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w, save_hin(pl.n_trunk - 1));
+                else gemm_hid<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w);
                 // the feature vector becomes an MFMA operand: move it out of the accumulator file (no ReLU)
                 relu_move<NT>(hin, acc, false);
-                if constexpr (TRAIN) store_acc_t8<NT>(tb, (uint32_t)a.tl.a_feat, hin);
                 f32x16 acc2[NT / 2];
                 load_bias<NT / 2>(acc2, wb, (uint32_t)pl.views_b);                               // network.py:58-62
-                gemm_hid<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid);
+                if constexpr (TRAIN) {
+                    uint32_t sec = (uint32_t)a.tl.a_feat;
+                    asm volatile("" : "+s"(sec));
+                    gemm_hid_side<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid,
+                                              [&](int G) { store_acc_t8_group<NT>(tb, sec, hin, G); });
+                } else {
+                    gemm_hid<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid);
+                }
                 // the direction encoding is built here, not at the top: 16 registers the trunk cannot spare
                 float din[kKsD];
                 if constexpr (EMB) {
@@ -122,6 +134,10 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 if (h == 0 && p < a.n_points) reinterpret_cast<float4 *>(a.raw)[p] = o;
             }
         } else {
+            if constexpr (TRAIN) {      // no GEMM consumes the last trunk layer here: save it in one go
+                store_acc_t8<NT>(tb, (uint32_t)a.tl.a_trunk + (pl.n_trunk - 1) * (32 * 32 * NT), hin);
+                store_gate_bits<NT>(tb, (uint32_t)a.tl.a_mask + (pl.n_trunk - 1) * 256, hin, lane);
+            }
             for (int o = 0; o < pl.output_ch; ++o) {                                             // network.py:67
                 float v = head_dot<NT>(hin, wb, (uint32_t)pl.out_vec + o * NT * 32) +
                           wload1(wb, ((uint32_t)pl.out_b + o) * 4);
