@@ -314,7 +314,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": pmc_traffic("render_bf16" if bf16 else "render",
-                                                "query_fwd_bf16_kernel" if bf16 else "query_fwd_kernel"),
+                                                "query_fwd_bf16_kernel<8>" if bf16
+                                                else "query_fwd_kernel<8, false, false, false>"),
                          "kernel": "query_fwd_bf16_kernel<8> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)" if bf16
                          else "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)",
                          "launches": q_n, "avg_launch_ms": q_ms / max(q_n, 1),

@@ -32,7 +32,7 @@ def main(tag, rnd):
             for k, v in json.load(open(p)).items():
                 if "at::" in k or "rocclr" in k or not k.endswith("_kernel") and "_kernel<" not in k:
                     continue
-                name = k.split("::")[-1].split("<")[0].strip()
+                name = k.replace("nrf::", "").strip()   # template arguments stay: instantiations are different kernels
                 e = per.setdefault(name, {})
                 e["launches"] = v[c]["launches"]
                 if c == "FETCH_SIZE":

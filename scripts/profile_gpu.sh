@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 RENDER="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-TRAIN="$ROOT/bench.py --workload train --steps 5 --warmup 2"
+TRAIN="$ROOT/bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline"
 for what in "$@"; do
   case $what in
     list)
@@ -18,7 +18,7 @@ for what in "$@"; do
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render" -o render -- python3 $RENDER > "$OUT/render_stats.log" 2>&1
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN > "$OUT/train_stats.log" 2>&1 ;;
     stats_train)
-      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN --no-cpu-baseline --no-extras > "$OUT/train_stats.log" 2>&1
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN --no-extras > "$OUT/train_stats.log" 2>&1
       head -6 "$OUT"/stats_train/train_kernel_stats.csv | cut -c1-150 ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
