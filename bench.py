@@ -182,6 +182,7 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
     for prec in ("fp32", "bf16"):
         a.precision = prec
         also[f"dnerf_{prec}"] = brief(bench_dnerf.run_dnerf(a, torch, dist, 1, 0, device, emit=False))
+    also["dnerf_train_step"] = bench_dnerf.run_dnerf_train(a, torch, device)
     return also
 
 

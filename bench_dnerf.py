@@ -111,3 +111,68 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
         dist.barrier()
         dist.destroy_process_group()
     return out if rank == 0 else None
+
+
+# fwd + bwd of the chain per point: both nets' forward, weight and activation gradients, minus the input-side
+# activation gradients that nothing consumes (time net: gamma(x), gamma(t) of layer 0 and the skip slice; canonical
+# net: the view slice) -- d/d(gamma(x')) of the canonical net IS consumed (it drives the time net).
+TRAIN_MAC = 3 * (TIME_MAC + OCC_MAC) - ((63 + 21) * 256 + 63 * 256) - 27 * 128
+
+
+def run_dnerf_train(args, torch, device, n_rays=1024, steps=10, warmup=3):
+    """One D-NeRF training step as vanilla_dynamic/train.py:237-277 runs it (bouncingballs_deform.txt: N_rand 1024,
+    64+128 samples, one DNeRF_Deformation for both passes, grad_clip 1.0): render_dnerf on a ray batch with per-ray
+    times -> mse(rgb) + mse(rgb0) -> backward through the canonical net into the deformation net -> clipped fused Adam.
+    Single GPU; returns the summary dict."""
+    import nerf_fixtures as fx
+    import nerf_amd.vanilla_dynamic as vd
+    from bench import PEAK_F32_MFMA_TFLOPS
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.utils import img2mse
+
+    embed_fn, _ = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = vd.get_time_embedder(10)
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                 input_ch_time=21, output_ch=5, skips=[4], use_viewdirs=True, zero_canonical=True)
+    sd = fx.make_dnerf_state(31, peaky=True, dx_scale=3.0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(device)
+    model.embed_fn = embed_fn
+    params = list(model.parameters())
+    opt = FusedAdam(params, lr=5e-4, betas=(0.9, 0.999))
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=1., N_importance=128, network_fine=None,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+    H = W = 400
+    K, _ = fx.intrinsics(H, W)
+    ro_np, rd_np, target_np = fx.train_batch(n_rays=n_rays * (steps + warmup), H=H, W=W, seed=7)
+    ro_all, rd_all = torch.from_numpy(ro_np).to(device), torch.from_numpy(rd_np).to(device)
+    target_all = torch.from_numpy(target_np).to(device)
+    times_all = torch.rand(n_rays * (steps + warmup), 1, device=device) * 0.9 + 0.05
+
+    def step(i):
+        sl = slice(i * n_rays, (i + 1) * n_rays)
+        rays = torch.stack([ro_all[sl], rd_all[sl]])
+        rgb, disp, acc, extras = vd.render_dnerf(H, W, K, times_all[sl], chunk=32768, rays=rays, near=2., far=6.,
+                                                 retraw=True, **kw)
+        opt.zero_grad()
+        loss = img2mse(rgb, target_all[sl]) + img2mse(extras['rgb0'], target_all[sl])
+        loss.backward()
+        opt.step(max_grad_norm=1.0)          # vanilla_dynamic/train.py:273-274
+        opt.param_groups[0]['lr'] = 5e-4 * 0.1 ** (i / 500000.0)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pts = n_rays * (64 + 192)
+    tf = pts * 2 * TRAIN_MAC / dt / 1e12
+    return {"value": n_rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
+            "roofline_frac": tf / PEAK_F32_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+            "workload": f"D-NeRF deformation training step, {n_rays}-ray batch with per-ray times, 64+128 samples, time net + "
+                        "canonical net D=8 W=256, fp32, forward+backward+clipped fused Adam"}

@@ -65,3 +65,44 @@ class RayBatcher:
             self.i_batch = 0
             self.epoch += 1
         return batch_rays, target_s
+
+
+class ImageRaySampler:
+    """The `no_batching` branch of train.py:194-224 (and vanilla_dynamic/train.py:205-235): N_rand random pixels of ONE
+    training image per step, optionally from the centre crop of the first `precrop_iters` iterations.  The reference
+    builds all H*W rays of the image with get_rays and indexes them; here only the chosen pixels' rays are built, by the
+    same gather kernel in its float32 mode (bit-identical to get_rays, rays.py:19-26)."""
+
+    def __init__(self, images, poses, H, W, K, device="cuda", reference_rng=False):
+        dev = torch.device(device)
+        images = torch.as_tensor(np.asarray(images) if not isinstance(images, torch.Tensor) else images)
+        poses = torch.as_tensor(np.asarray(poses) if not isinstance(poses, torch.Tensor) else poses)
+        self.images = images[..., :3].to(dev, torch.float32).contiguous()
+        self.poses = poses[:, :3, :4].to(dev, torch.float32).contiguous()
+        self.H, self.W, self.K = int(H), int(W), [[float(v) for v in r] for r in np.asarray(K)]
+        self.reference_rng = bool(reference_rng)
+
+    def crop_pixels(self, precrop_frac=None):
+        """Flat pixel indices (y*W + x) of the candidate set, in the reference's order (train.py:204-218)."""
+        H, W = self.H, self.W
+        if precrop_frac is None:
+            return None
+        dH, dW = int(H // 2 * precrop_frac), int(W // 2 * precrop_frac)
+        ys = torch.arange(H // 2 - dH, H // 2 + dH, device=self.images.device)
+        xs = torch.arange(W // 2 - dW, W // 2 + dW, device=self.images.device)
+        return (ys[:, None] * W + xs[None, :]).reshape(-1)
+
+    def sample(self, img_i, N_rand, precrop_frac=None, select_inds=None):
+        """-> (batch_rays [2, N_rand, 3], target_s [N_rand, 3]).  select_inds: positions in the candidate set (what
+        np.random.choice returns at train.py:219); drawn here when None."""
+        cand = self.crop_pixels(precrop_frac)
+        n = self.H * self.W if cand is None else cand.numel()
+        if select_inds is None:
+            if self.reference_rng:
+                select_inds = torch.from_numpy(np.random.choice(n, size=[N_rand], replace=False))
+            else:
+                select_inds = torch.randperm(n, device=self.images.device)[:N_rand]
+        select_inds = torch.as_tensor(select_inds).to(self.images.device, torch.int64)
+        pix = select_inds if cand is None else cand[select_inds]
+        rows = pix + int(img_i) * self.H * self.W
+        return ops.gather_ray_batch(rows, self.images, self.poses, self.H, self.W, self.K, f64=False)

@@ -109,6 +109,33 @@ def test_batcher_reference_rng_and_rank_slices(tab):
     assert torch.equal(got[0], whole[0]) and torch.equal(got[1], whole[1])
 
 
+def test_image_ray_sampler_is_get_rays_indexing(tab):
+    """no_batching branch (train.py:194-224): get_rays of the image, then [select_coords]; with and without precrop."""
+    from nerf_amd.raybatch import ImageRaySampler
+    from nerf_amd.rays import get_rays
+    H, W, K, images, poses, _ = _scene(tab)
+    s = ImageRaySampler(tab["table_images"], tab["table_poses"], H, W, tab["table_K"])
+    ro, rd = get_rays(H, W, K, poses[1, :3, :4])
+    for frac in (None, 0.5):
+        if frac is None:
+            coords = torch.stack(torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij"), -1)
+        else:
+            dH, dW = int(H // 2 * frac), int(W // 2 * frac)
+            coords = torch.stack(torch.meshgrid(torch.linspace(H // 2 - dH, H // 2 + dH - 1, 2 * dH),
+                                                torch.linspace(W // 2 - dW, W // 2 + dW - 1, 2 * dW), indexing="ij"), -1)
+        coords = coords.reshape(-1, 2)
+        sel = np.random.RandomState(5).choice(coords.shape[0], size=[min(6, coords.shape[0])], replace=False)
+        sc = coords[sel].long()
+        rays, tgt = s.sample(1, len(sel), precrop_frac=frac, select_inds=sel)
+        np.testing.assert_array_equal(bits(rays[0].cpu().numpy()), bits(ro[sc[:, 0], sc[:, 1]].cpu().numpy()))
+        # torch's GPU sum may contract differently from the reference's CPU order the kernel follows (<= 1 ulp); the
+        # bit-exact statement is test_gather_f32_mode_is_get_rays (against the golden-pinned ray-matrix kernel)
+        np.testing.assert_allclose(rays[1].cpu().numpy(), rd[sc[:, 0], sc[:, 1]].cpu().numpy(), rtol=0, atol=5e-7)
+        np.testing.assert_array_equal(tgt.cpu().numpy(), tab["table_images"][1][sc[:, 0].numpy(), sc[:, 1].numpy()])
+    rays, tgt = s.sample(2, 10)
+    assert rays.shape == (2, 10, 3) and tgt.shape == (10, 3) and torch.isfinite(rays).all()
+
+
 def test_checkpoint_to_modules_and_packed(tab):
     from nerf_amd import checkpoint as ck
     nets = ck.networks_from_checkpoint(CKPT, device="cuda")
