@@ -411,9 +411,11 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
 }
 
 // View-direction head of the canonical net (network.py:56-65) -> (rgb + alpha) of both point tiles, stored by lane half 0.
+// `din` = gamma(d), built by the caller BEFORE the trunk: 16 registers held through it cost nothing, while building it here
+// (its sincos temporaries on top of the live feature operand) spilled 60 registers.
 template <int NT>
 __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v &one, WStream &st,
-                                              const float *hb, const float (&dv)[2][3], const int64_t (&pp)[2],
+                                              const float *hb, const u32x4v (&din)[2][kBfKsD], const int64_t (&pp)[2],
                                               const int64_t (&pc)[2], int64_t n_points, int pts_per_ray, int h, float *raw,
                                               long long *prof = nullptr) {
     (void)prof;
@@ -429,9 +431,6 @@ __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin
     gemm_layer<NT, 2 * NT + 1>(acc, st, Hb);                                               // network.py:57
     pack_acts<NT>(hin, acc, false);
     PROF_T(h2);
-    u32x4v din[2][kBfKsD];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) fill_pe3_bf16<kBfKsD>(din[p], dv[p][0], dv[p][1], dv[p][2], h);
     PROF_T(h3);
     PROF_ADD(6, h2, h3);
     f32x16 acc2[2][NT / 2];
@@ -464,7 +463,8 @@ struct Bf16Args {
 };
 
 
-template <int NT>
+// VIEWS is a template parameter: with both heads in one kernel the allocator spilled another 49 registers.
+template <int NT, bool VIEWS>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -490,16 +490,16 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         PROF_T(ta);
         int64_t pp[2], pc[2];
-        float dv[2][3] = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}};
         u32x4v xin[2][kBfKsX];
+        u32x4v din[2][VIEWS ? kBfKsD : 1];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             pp[p] = tile * 256 + st.wave * 64 + p * 32 + n;
             pc[p] = pp[p] < a.n_points ? pp[p] : a.n_points - 1;
             const float *q = a.pts + pc[p] * 3;
-            if (a.use_viewdirs) {   // issued here, used after the trunk: the load's latency disappears behind it
+            if constexpr (VIEWS) {
                 const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
-                dv[p][0] = d[0]; dv[p][1] = d[1]; dv[p][2] = d[2];
+                fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
             }
             fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], h);
         }
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
         bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.n_trunk, a.skip_in_mask,
                              [&](int p, int s) { return as_bf(xin[p][s]); }, prof);               // network.py:48-53
         PROF_T(tc);
-        if (a.use_viewdirs) {
-            bf_views_head<NT>(acc, hin, one, st, hb, dv, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
+        if constexpr (VIEWS) {
+            bf_views_head<NT>(acc, hin, one, st, hb, din, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
             PROF_T(td);
             PROF_ADD(3, tc, td);
         } else {
@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const Dner
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int64_t pp[2], pc[2];
         float px[2][3], dv[2][3];
+        u32x4v din[2][kBfKsD];
         bool skip[2];
         u32x4v xin[2][kBfKsX], tin[2][kBfKsT];
 #pragma unroll
@@ -632,10 +633,11 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const Dner
                     a.dx[pp[p] * 3 + 0] = d[0]; a.dx[pp[p] * 3 + 1] = d[1]; a.dx[pp[p] * 3 + 2] = d[2];
                 }
                 fill_pe3_bf16<kBfKsX>(xin[p], px[p][0], px[p][1], px[p][2], h);                   // network.py:332-333
+                fill_pe3_bf16<kBfKsD>(din[p], dv[p][0], dv[p][1], dv[p][2], h);   // here: gamma(t) is dead, the trunk spare
             }
         }
         bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.c_trunk, a.c_skip_mask, [&](int p, int s) { return as_bf(xin[p][s]); });
-        bf_views_head<NT>(acc, hin, one, st, hb, dv, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
+        bf_views_head<NT>(acc, hin, one, st, hb, din, pp, pc, a.n_points, a.pts_per_ray, h, a.raw);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -762,8 +764,13 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
     hipStream_t st = as_stream(stream);
     switch (net->W / 32) {
         case 8:
-            hipLaunchKernelGGL((query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((query_fwd_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, a); break;
+            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((query_fwd_bf16_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a);
+            break;
+        case 4:
+            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((query_fwd_bf16_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a);
+            break;
     }
     return check_launch("nrf_query_fwd_bf16");
 }
