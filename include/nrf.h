@@ -69,12 +69,13 @@ int nrf_gen_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, c
  * rays.py:30-49 of every training pose, stacked with the image), :183-185 (batch = rows i_batch .. i_batch+N_rand).
  * rows [n]: DEVICE int64 rows of the UNSHUFFLED table, row = slot * H*W + y*W + x (the caller owns the permutation);
  * img_index [n_slots] (i_train; NULL = identity); poses: image i at poses + i*pose_pitch, 3 rows of >= 4 floats
- * `pose_stride` apart; images [*, H, W, 3] f32.  f64 = 1: float64 arithmetic rounded once (what NumPy >= 2 computes for a
+ * `pose_stride` apart; images [n_images, H, W, 3] f32.  f64 = 1: float64 arithmetic rounded once (what NumPy >= 2 computes for a
  * float64 K), 0: float32 (NumPy 1.x / get_rays order).  rays [2, n, 3] (origins, directions), rgb [n, 3].
- * Rows outside the table produce NaN. */
+ * Rows outside the table, and slots whose img_index entry is not in [0, n_images), produce NaN. */
 int nrf_gather_ray_batch(const int64_t *rows, int64_t n, const int32_t *img_index, int32_t n_slots, const float *poses,
-                         int32_t pose_stride, int64_t pose_pitch, const float *images, int32_t H, int32_t W, double fx,
-                         double fy, double cx, double cy, int32_t f64, float *rays, float *rgb, void *stream);
+                         int32_t pose_stride, int64_t pose_pitch, const float *images, int32_t n_images, int32_t H,
+                         int32_t W, double fx, double fy, double cx, double cy, int32_t f64, float *rays, float *rgb,
+                         void *stream);
 
 /* K1  coarse depths  -- render.py:186-208 (linspace, near/far lerp or lindisp, optional stratified jitter)
  * rays [N, ncol] = o(3) d(3) near far [viewdirs(3)]  (render.py:181-184); t_rand: NULL (perturb == 0) or

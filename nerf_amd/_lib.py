@@ -66,7 +66,7 @@ _SIGS = {
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float,
                                C.c_float, vp, vp]),
     "nrf_gather_ray_batch": (C.c_int, [vp, C.c_int64, vp, C.c_int32, vp, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32,
-                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp, vp, vp]),
+                                       C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp, vp, vp]),
     "nrf_adam_step": (C.c_int, [C.c_int32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 vp, vp]),
     "nrf_composite_fwd": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp,

@@ -334,7 +334,7 @@ struct RayBatchArgs {
     const int32_t *img_index;        // table slot -> image / pose index (i_train); null = identity
     const float *poses, *images;     // poses: 3 rows of >= 4 floats per image; images [*, H, W, 3]
     int64_t n, pose_pitch;
-    int32_t pose_stride, H, W, n_slots, f64;
+    int32_t pose_stride, H, W, n_slots, n_images, f64;
     double fx, fy, cx, cy;
     float *rays, *rgb;               // [2, n, 3], [n, 3]
 };
@@ -352,6 +352,11 @@ __global__ void __launch_bounds__(256) ray_batch_kernel(const RayBatchArgs a) {
         const int slot = (int)(r / hw);
         const int64_t pix = r - slot * hw;
         const int img = a.img_index ? a.img_index[slot] : slot;
+        if (img < 0 || img >= a.n_images) {   // a slot that names no image
+            const float q = __builtin_nanf("");
+            for (int k = 0; k < 3; ++k) { ro[k] = q; rd[k] = q; c[k] = q; }
+            continue;
+        }
         const float col = (float)(pix % a.W), row = (float)(pix / a.W);
         const float *m = a.poses + img * a.pose_pitch;
         if (a.f64) {
@@ -376,15 +381,16 @@ __global__ void __launch_bounds__(256) ray_batch_kernel(const RayBatchArgs a) {
 
 extern "C" int nrf_gather_ray_batch(const int64_t *rows, int64_t n, const int32_t *img_index, int32_t n_slots,
                                     const float *poses, int32_t pose_stride, int64_t pose_pitch, const float *images,
-                                    int32_t H, int32_t W, double fx, double fy, double cx, double cy, int32_t f64,
-                                    float *rays, float *rgb, void *stream) {
-    NRF_REQUIRE(H >= 1 && W >= 1 && n >= 0 && n_slots >= 1, "nrf_gather_ray_batch: bad image / table size");
+                                    int32_t n_images, int32_t H, int32_t W, double fx, double fy, double cx, double cy,
+                                    int32_t f64, float *rays, float *rgb, void *stream) {
+    NRF_REQUIRE(H >= 1 && W >= 1 && n >= 0 && n_slots >= 1 && n_images >= 1, "nrf_gather_ray_batch: bad image / table size");
+    NRF_REQUIRE(img_index || n_slots <= n_images, "nrf_gather_ray_batch: more table slots than images");
     NRF_REQUIRE(pose_stride >= 4 && pose_pitch >= 2 * (int64_t)pose_stride + 4, "nrf_gather_ray_batch: pose layout");
     if (n == 0) return NRF_OK;
     NRF_REQUIRE(rows && poses && images && rays && rgb, "nrf_gather_ray_batch: null pointer");
     RayBatchArgs a{};
     a.rows = rows; a.img_index = img_index; a.poses = poses; a.images = images; a.n = n; a.pose_pitch = pose_pitch;
-    a.pose_stride = pose_stride; a.H = H; a.W = W; a.n_slots = n_slots; a.f64 = f64;
+    a.pose_stride = pose_stride; a.H = H; a.W = W; a.n_slots = n_slots; a.n_images = n_images; a.f64 = f64;
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.rays = rays; a.rgb = rgb;
     hipLaunchKernelGGL(ray_batch_kernel, dim3(nrf::grid_for(n, 256)), dim3(256), 0, nrf::as_stream(stream), a);
     return nrf::check_launch("nrf_gather_ray_batch");

@@ -74,7 +74,8 @@ def gather_ray_batch(rows, images, poses, H, W, K, img_index=None, f64=True):
     rays = torch.empty((2, n, 3), device=images.device, dtype=torch.float32)
     rgb = torch.empty((n, 3), device=images.device, dtype=torch.float32)
     check(_lib.lib().nrf_gather_ray_batch(_ptr(rows), n, _ptr(img_index), int(n_slots), _ptr(poses), int(poses.stride(1)),
-                                          int(poses.stride(0)), _ptr(images), int(H), int(W), float(K[0][0]),
+                                          int(poses.stride(0)), _ptr(images), int(images.shape[0]), int(H), int(W),
+                                          float(K[0][0]),
                                           float(K[1][1]), float(K[0][2]), float(K[1][2]), int(bool(f64)), _ptr(rays),
                                           _ptr(rgb), _stream()), "nrf_gather_ray_batch")
     return rays, rgb

@@ -58,6 +58,9 @@ def test_gather_edges(tab):
     bad = torch.isnan(rgb).all(dim=1).cpu().numpy()
     np.testing.assert_array_equal(bad, [False, True, True, False])
     assert torch.isnan(rays[:, 1]).all() and torch.isnan(rays[:, 2]).all()
+    bad_map = torch.tensor([0, 7, -1], dtype=torch.int32, device="cuda")          # slots 1, 2 name no image
+    rays, rgb = ops.gather_ray_batch(torch.tensor([0, H * W, 2 * H * W], device="cuda"), images, poses, H, W, K, bad_map)
+    np.testing.assert_array_equal(torch.isnan(rgb).all(dim=1).cpu().numpy(), [False, True, True])
     with pytest.raises(RuntimeError):
         ops.gather_ray_batch(rows.int(), images, poses, H, W, K, i_train)
     with pytest.raises(ValueError):
