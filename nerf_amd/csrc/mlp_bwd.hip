@@ -271,7 +271,11 @@ struct WgradArgs {
     int32_t chunk_tiles, nchunks;
 };
 
-constexpr int kWgStage = 16384;
+#ifndef NRF_WG_M
+#define NRF_WG_M 2
+#endif
+constexpr int kWgM = NRF_WG_M;                // 8-point groups per step: a step covers 8 * kWgM points of one tile
+constexpr int kWgStage = 16384 * kWgM;        // per group: <= 8 G pieces then <= 8 X pieces of 1 KiB
 
 // The step loop of wgrad_kernel for a wave that owns NA x KA tiles (0 x 0: a wave with no tiles still copies its share
 // of the pieces and takes part in the barriers).  Fragments are double-buffered in registers: step s+1's are read from
@@ -284,13 +288,16 @@ template <int NA, int KA, class Req>
 __device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
                                             int64_t nsteps, Req &&request) {
     constexpr int NAr = NA ? NA : 1, KAr = KA ? KA : 1;
-    f32x4 A0[NAr], B0[KAr], A1[NAr], B1[KAr];
-    auto read_frags = [&](f32x4 (&A)[NAr], f32x4 (&B)[KAr], int stage) {
-        const char *base = lds + stage * kWgStage + lane * 16;
+    f32x4 A0[kWgM][NAr], B0[kWgM][KAr], A1[kWgM][NAr], B1[kWgM][KAr];
+    auto read_frags = [&](f32x4 (&A)[kWgM][NAr], f32x4 (&B)[kWgM][KAr], int stage) {
 #pragma unroll
-        for (int x = 0; x < NA; ++x) A[x] = *reinterpret_cast<const f32x4 *>(base + (nt0 + x) * 1024);
+        for (int m = 0; m < kWgM; ++m) {
+            const char *base = lds + stage * kWgStage + m * 16384 + lane * 16;
 #pragma unroll
-        for (int y = 0; y < KA; ++y) B[y] = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
+            for (int x = 0; x < NA; ++x) A[m][x] = *reinterpret_cast<const f32x4 *>(base + (nt0 + x) * 1024);
+#pragma unroll
+            for (int y = 0; y < KA; ++y) B[m][y] = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
+        }
     };
     auto land = [&]() {   // own copies have landed; after the barrier everyone's have
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -298,21 +305,24 @@ __device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[4][4], float (&bs)[4],
         asm volatile("" ::: "memory");
     };
     int st_nxt = 1, st_req = 2;
-    auto body = [&](int64_t step, f32x4 (&A)[NAr], f32x4 (&B)[KAr], f32x4 (&An)[NAr], f32x4 (&Bn)[KAr]) {
+    auto body = [&](int64_t step, f32x4 (&A)[kWgM][NAr], f32x4 (&B)[kWgM][KAr], f32x4 (&An)[kWgM][NAr],
+                    f32x4 (&Bn)[kWgM][KAr]) {
         land();
         if (step + 2 < nsteps) request(step + 2, st_req);   // first: its latency is the step's critical path
         if constexpr (NA > 0 && KA > 0) {
             read_frags(An, Bn, st_nxt);     // past the last step this re-reads a stale stage: unused
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int x = 0; x < NA; ++x) {
-                bs[x] += (A[x][0] + A[x][1]) + (A[x][2] + A[x][3]);
+            for (int m = 0; m < kWgM; ++m)
 #pragma unroll
-                for (int y = 0; y < KA; ++y)
+                for (int x = 0; x < NA; ++x) {
+                    bs[x] += (A[m][x][0] + A[m][x][1]) + (A[m][x][2] + A[m][x][3]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x][j], B[y][j], acc[x][y], 0, 0, 0);
-            }
+                    for (int y = 0; y < KA; ++y)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m][x][j], B[m][y][j], acc[x][y], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
@@ -320,7 +330,7 @@ __device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[4][4], float (&bs)[4],
     };
     if (nsteps > 0) {
         request(0, 0);
-        request(1, 1);          // nsteps is a multiple of 4
+        request(1, 1);          // nsteps is even
         land();
         if constexpr (NA > 0 && KA > 0) read_frags(A0, B0, 0);
     }
@@ -366,12 +376,13 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
 
     const int64_t t0 = (int64_t)chunk * a.chunk_tiles;
     const int64_t t1 = min(a.ntiles, t0 + a.chunk_tiles);
-    const int64_t nsteps = (t1 - t0) * 4;   // one step = 8 points (m) of one tile
+    constexpr int kSpt = 4 / kWgM;                 // steps per 32-point tile
+    const int64_t nsteps = (t1 - t0) * kSpt;       // one step = kWgM groups of 8 points of one tile
 
     // copy this wave's share of step `step`'s pieces into `stage`: piece i (G pieces first, then X) by wave i & 3
     auto request = [&](int64_t step, int stage) {
-        const int64_t tile = t0 + (step >> 2);
-        const int m = (int)(step & 3);
+        const int64_t tile = t0 + step / kSpt;
+        const int m0 = (int)(step % kSpt) * kWgM;
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.gbuf) + tile * a.g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
 #pragma unroll
@@ -379,16 +390,21 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
             const int i = wib + 4 * q;
             char *dst = lds + stage * kWgStage + i * 1024;
             if (i < gn) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)dst, 16, lane_src,
-                                                         ((m * a.Cg + 32 * (nsb * 8 + i)) * 8) * 4, 0, 0);
+#pragma unroll
+                for (int mm = 0; mm < kWgM; ++mm)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
+                                                             16, lane_src,
+                                                             (((m0 + mm) * a.Cg + 32 * (nsb * 8 + i)) * 8) * 4, 0, 0);
             } else if (i - 8 < xn && i >= 8) {
                 const int kt = ksb * 8 + (i - 8);
                 const int sec = kt >= a.k_tiles0;
                 const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
                 __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(a.acts) + tile * a.a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 4, 0x00020000);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)dst, 16, lane_src,
-                                                         ((m * a.Ca[sec] + c0) * 8) * 4, 0, 0);
+#pragma unroll
+                for (int mm = 0; mm < kWgM; ++mm)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
+                                                             16, lane_src, (((m0 + mm) * a.Ca[sec] + c0) * 8) * 4, 0, 0);
             }
         }
     };
