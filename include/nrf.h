@@ -108,7 +108,7 @@ int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *pac
  * Workspaces are caller-allocated; sizes in floats from the *_floats queries (<= 0: unsupported shape).
  *   acts : inputs and per-layer activations saved by the forward        (~10.1 KB / point at W=256, D=8)
  *   gbuf : per-layer gradients w.r.t. pre-activations (backward scratch) (~10.0 KB / point)
- *   slab : per-chunk partial weight gradients (backward scratch)         */
+ *   slab : per-chunk partial weight gradients, one region per nn.Linear (backward scratch; <= 1.1 GB at W=256, D=8) */
 int64_t nrf_train_acts_floats(const nrf_net_t *net, int64_t n_points);
 int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points);
 int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points);

@@ -11,6 +11,7 @@
 //     Bias gradients are the row sums of the same A operand.
 //  3. reduce + unpack: sums the slabs over chunks (fixed order: deterministic) and scatters into the
 //     nn.Linear [out, in] gradient layout, undoing the k-space permutation of the input blocks.
+#include <algorithm>
 #include <type_traits>
 
 #include "mlp_device.h"
@@ -466,7 +467,13 @@ struct ReduceArgs {
 
 // Bandwidth-bound (nchunks x dW bytes): 4 lanes share one output quad, each summing a quarter of the chunks with
 // 8 float4 loads in flight, combined by shuffles in a FIXED order (bit-reproducible gradients).
-__global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceArgs a) {
+constexpr int kReduceBatch = 24;
+struct ReduceBatch { ReduceArgs e[kReduceBatch]; };
+
+// All reductions of a backward pass in one launch: blockIdx.y picks the entry (every GEMM keeps its own slab region,
+// so nothing is reused between them); blocks beyond an entry's work leave at once.
+__global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceBatch batch) {
+    const ReduceArgs &a = batch.e[blockIdx.y];
     const int kq = a.kn >> 2;                       // quads per row (kn is a multiple of 32)
     const int total_q = a.n_valid * kq;
     const int sub = threadIdx.x & 3;
@@ -528,13 +535,24 @@ struct Bwd {
     int64_t ntiles;
     int nchunks, chunk_tiles;
     hipStream_t st;
+    int64_t slab_off = 0, slab_cap = 0;    // floats: every GEMM gets its own region of `slab`
+    ReduceBatch batch;
+    int nbatch = 0, max_blocks = 1;
 
-    // One wgrad GEMM (a whole nn.Linear: G x cat[X parts]) + its reductions.
+    int flush() {   // the reductions collected so far, one launch
+        if (nbatch == 0) return NRF_OK;
+        hipLaunchKernelGGL(reduce_unpack_kernel, dim3(max_blocks, nbatch), dim3(256), 0, st, batch);
+        nbatch = 0; max_blocks = 1;
+        return check_launch("nrf_query_bwd (slab reduction)");
+    }
+
+    // One wgrad GEMM (a whole nn.Linear: G x cat[X parts]); its reductions are queued for flush().
     struct Dst { int row0, n_valid; const float *w; const float *b; };
     struct XPart { int64_t sec; int C, tiles, type, param, ks, k_valid, ch_off; };   // a T8 section and how its columns unpack
     int run(int64_t g_sec, int Cg, int n_tiles, const XPart *xp, int nparts, int ld, const Dst *dsts, int ndst) {
         WgradArgs w{};
-        w.gbuf = gbuf; w.acts = acts; w.slab = slab;
+        float *region = slab + slab_off;
+        w.gbuf = gbuf; w.acts = acts; w.slab = region;
         w.g_tile = tl.g_tile; w.a_tile = tl.a_tile; w.g_sec = g_sec;
         w.ntiles = ntiles; w.Cg = Cg; w.n_tiles = n_tiles;
         w.a_sec[0] = xp[0].sec; w.Ca[0] = xp[0].C; w.k_tiles0 = xp[0].tiles; w.k_tiles = xp[0].tiles;
@@ -542,12 +560,16 @@ struct Bwd {
         if (nparts > 1) { w.a_sec[1] = xp[1].sec; w.Ca[1] = xp[1].C; w.k_tiles += xp[1].tiles; }
         w.chunk_tiles = chunk_tiles; w.nchunks = nchunks;
         const int sblks = ((n_tiles + 7) / 8) * ((w.k_tiles + 7) / 8);
+        slab_off += (int64_t)nchunks * ((int64_t)n_tiles * 32 * w.k_tiles * 32 + n_tiles * 32);
+        if (slab_off > slab_cap) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: slab workspace too small (internal)");
         hipLaunchKernelGGL(wgrad_kernel, dim3(nchunks, sblks), dim3(256), 0, st, w);
         for (int i = 0; i < ndst; ++i) {
             int kc = 0;
             for (int q = 0; q < nparts; ++q) {
-                ReduceArgs r{};
-                r.slab = slab; r.dst_w = const_cast<float *>(dsts[i].w);
+                if (nbatch == kReduceBatch) { int rc = flush(); if (rc) return rc; }
+                ReduceArgs &r = batch.e[nbatch++];
+                r = ReduceArgs{};
+                r.slab = region; r.dst_w = const_cast<float *>(dsts[i].w);
                 r.dst_b = q == 0 ? const_cast<float *>(dsts[i].b) : nullptr;
                 r.nchunks = nchunks; r.NP = n_tiles * 32; r.KP = w.k_tiles * 32; r.row0 = dsts[i].row0;
                 r.n_valid = dsts[i].n_valid; r.ld = ld; r.ch_off = xp[q].ch_off;
@@ -555,7 +577,7 @@ struct Bwd {
                 r.kc = kc; r.kn = xp[q].tiles * 32;
                 kc += r.kn;
                 int total_q = r.n_valid * (r.kn / 4) + r.n_valid + 4;
-                hipLaunchKernelGGL(reduce_unpack_kernel, dim3(grid_for(total_q, 64, 4096)), dim3(256), 0, st, r);
+                max_blocks = std::max(max_blocks, (int)grid_for(total_q, 64, 4096));
             }
         }
         return check_launch("nrf_query_bwd (wgrad)");
@@ -582,8 +604,10 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
     if (!net || net->W % 32 || n_points < 0) return -1;
     int ct;
     int64_t nchunks = pick_chunks((n_points + 31) / 32, &ct);
-    int64_t np = net->W + 32, kp = net->W + 2 * kKsX;  // bound on every GEMM: (feature + alpha row) x cat[hidden, gamma(x)]
-    return nchunks * (np * kp + np);
+    // every GEMM of the pass (<= D trunk layers + 3 heads) keeps its own slab region; bound on each:
+    // (feature + alpha row) x cat[hidden, gamma(x), gamma(t)]
+    int64_t np = net->W + 32, kp = net->W + 2 * kKsX + 32;
+    return nchunks * (net->D + 3) * (np * kp + np);
 }
 
 // time_ch > 0: `net` describes a deformation ("time") net (layer 0 also reads gamma(t)).  pts/g_pts non-null: also
@@ -635,6 +659,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
     B.ntiles = ntiles; B.st = st;
     B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles);
+    B.slab_cap = nrf_train_slab_floats(net, n_points);
     const TrainLayout &tl = d.tl;
     const int xk = 2 * kKsX / 32, dk = 2 * kKsD / 32;  // 32-channel tiles of the k-space input blocks
     const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};
@@ -680,7 +705,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
         rc = B.run(tl.g_head, 32, 1, &Hlast, 1, W, &od, 1);
         if (rc) return rc;
     }
-    return NRF_OK;
+    return B.flush();
 }
 
 extern "C" int nrf_query_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
