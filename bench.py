@@ -315,9 +315,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": pmc_traffic("render_bf16" if bf16 else "render",
-                                                "query_fwd_bf16_kernel<8>" if bf16
+                                                "query_fwd_bf16_kernel<8, true>" if bf16
                                                 else "query_fwd_kernel<8, false, false, false>"),
-                         "kernel": "query_fwd_bf16_kernel<8> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)" if bf16
+                         "kernel": "query_fwd_bf16_kernel<8,true> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)" if bf16
                          else "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)",
                          "launches": q_n, "avg_launch_ms": q_ms / max(q_n, 1),
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": q_pts / max(q_n, 1),
