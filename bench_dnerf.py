@@ -81,7 +81,7 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
     dt = time.perf_counter() - t0
     enabled[0] = False
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     out = None

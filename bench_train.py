@@ -77,13 +77,13 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     out = None
     if rank == 0:
         pts = n_global * 256
-        achieved = pts * STEP_FLOP_PER_POINT * args.steps / dt / 1e12
+        achieved = (pts / world) * STEP_FLOP_PER_POINT * args.steps / dt / 1e12      # per GPU: the roofline is one GPU's
         out = {
             "metric": "rays/sec at 64+128 samples/ray (train step)",
             "value": n_global * args.steps / dt,
@@ -95,8 +95,8 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
                        "parallelism": f"dp{world}, one flat all-reduce (4.77 MB)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": step_traffic(),
-                         "kernel": "whole step (query_fwd<train> + dgrad + wgrad kernels); algorithmic "
-                                   "3.489 MFLOP/point over wall time; traffic = HBM bytes per STEP over all kernels"},
+                         "kernel": "whole step (query_fwd<train> + dgrad + wgrad kernels), per GPU; algorithmic "
+                                   "3.489 MFLOP/point over wall time; traffic = HBM bytes per 4096-ray STEP over all kernels"},
         }
         if emit:
             print(json.dumps(out), flush=True)

@@ -40,11 +40,14 @@ def render_sharded(render_rows, H, W, rank=None, world=None, group=None):
     maxrows = max(n for _, n in parts)
     buf = mine.new_zeros((maxrows * W, C))
     buf[: nrows * W] = mine
+    dev = buf.device
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        buf = buf.cpu()             # gloo gathers host tensors only (CPU tests, rehearsals); RCCL gathers in place
     gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, gathered, dst=0, group=group)
     if rank != 0:
         return None
-    return torch.cat([g[: n * W] for g, (_, n) in zip(gathered, parts)], 0).reshape(H, W, C)
+    return torch.cat([g[: n * W] for g, (_, n) in zip(gathered, parts)], 0).reshape(H, W, C).to(dev)
 
 
 def render_rows(H, W, K, c2w, row0, nrows, chunk=1024 * 32, ndc=True, near=0., far=1., use_viewdirs=False,
@@ -78,7 +81,12 @@ class FlatGradAllReduce:
             p.grad = torch.zeros_like(p)
         grads = [p.grad for p in self.params]
         self.flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":   # CPU tests / rehearsals: staged on the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / world)
         pieces = [t.view_as(g) for t, g in zip(self.flat.split([g.numel() for g in grads]), grads)]
         torch._foreach_copy_(grads, pieces)
