@@ -112,6 +112,13 @@ def test_bf16_render_within_1e2(gold):
     both = stable & stable0
     psnr = -10 * np.log10(np.mean((host(ret["rgb_map"])[both] - gold["rr_smooth_rgb_map"][both]) ** 2) + 1e-30)
     assert psnr > 45.0, psnr
+    # the north star's "PSNR delta <= 0.05 dB" (no lego data offline, so against a common synthetic target):
+    # a ground truth at ~26 dB from the reference image (the README's lego/fern quality level) scores the bf16 image and
+    # the reference image within 0.05 dB of each other
+    target = gold["rr_smooth_rgb_map"][both] + np.random.RandomState(0).normal(0, 0.05, gold["rr_smooth_rgb_map"][both].shape)
+    p_ref = -10 * np.log10(np.mean((gold["rr_smooth_rgb_map"][both] - target) ** 2))
+    p_b16 = -10 * np.log10(np.mean((host(ret["rgb_map"])[both] - target) ** 2))
+    assert 25.0 < p_ref < 27.5 and abs(p_b16 - p_ref) <= 0.05, (p_ref, p_b16)
 
 
 def test_bf16_training_uses_f32():
