@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B of library variants on ONE box (run through gpurun): build variants into scratch/<name>.so, then
+#   bash scripts/ab_variants.sh a.so b.so      -> per-kernel ms per training step from rocprofv3 stats, two rounds
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for round in 1 2; do
+for v in "$@"; do
+  cp $R/scratch/$v $R/nerf_amd/libnrf.so
+  rm -rf /tmp/ab_$v
+  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -o t -- python3 $R/bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /tmp/ab_$v.log 2>&1
+  python3 - "$v" /tmp/ab_$v/t_kernel_stats.csv <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[2])):
+    n = r["Name"]
+    if any(k in n for k in ("wgrad", "query_fwd", "dgrad")):
+        print(sys.argv[1], n.split("(")[0][-40:], "%.3f ms/step" % (float(r["TotalDurationNs"]) / 7 / 1e6))
+PY
+done; done
