@@ -201,9 +201,10 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
         }
         // trunk in reverse (network.py:49-53)
         u32x4 gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (pl.n_trunk - 1) * 256, lane);
+        apply_gate_bits<NT>(gate, g);
         for (int l = pl.n_trunk - 1; l >= 0; --l) {
-            apply_gate_bits<NT>(gate, g);
-            if (l > 0) gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);   // in flight during this layer's GEMM
+            // g = gated gradient w.r.t. layer l's pre-activations; the next layer's gates are in flight during this GEMM
+            if (l > 0) gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);
             if constexpr (GX) {
                 if (l == 0 || ((pl.skip_in_mask >> l) & 1)) {   // g_x += W_l[:, :input_ch]^T g_l
                     --xi;
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
                 const int voff = t8c_voff(tg, W);
                 gemm_hid_side<NT, NT>(nx, g, wb, (uint32_t)(pl.trunkT_base + (int64_t)(l - 1) * pl.trunkT_stride),
                                       [&](int G) { store_acc_t8c_group<NT>(tg, sec, voff, g, G); });
-                relu_move<NT>(g, nx, false);
+                move_gated<NT>(g, nx, gate);     // through layer l-1's ReLU, on the way out of the accumulators
             } else {
                 store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk, W, g);      // layer 0's block has no consumer
             }

@@ -424,6 +424,20 @@ __device__ __forceinline__ void apply_gate_bits(const u32x4 &m, f32x16 (&g)[NT])
             g[t][r] = (int32_t)(m[t >> 1] << (16 * (t & 1) + r)) < 0 ? g[t][r] : 0.0f;
 }
 
+// dst = gate ? src : 0 in ONE pass out of the accumulator file (relu_move + apply_gate_bits fused): the gate bit is
+// sign-extended into a mask (v_bfe_i32) and ANDed onto the value's bits -- two VALU ops per value beside the
+// accumulator read, instead of a move pass (read, max) followed by a gate pass (shift, compare, select).
+template <int NT>
+__device__ __forceinline__ void move_gated(f32x16 (&dst)[NT], const f32x16 (&src)[NT], const u32x4 &m) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mask = __builtin_amdgcn_sbfe((int)m[t >> 1], 31 - (16 * (t & 1) + r), 1);
+            dst[t][r] = __uint_as_float(__float_as_uint(src[t][r]) & (uint32_t)mask);
+        }
+}
+
 template <int NT>
 __device__ __forceinline__ void load_acc_t8(const TBuf &tb, uint32_t sec, f32x16 (&v)[NT]) {
     constexpr int C = 32 * NT;
