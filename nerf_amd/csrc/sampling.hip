@@ -69,12 +69,16 @@ __global__ void __launch_bounds__(256) points_kernel(const float *__restrict__ r
 constexpr int kMaxBins = 256;     // S-1 <= 256
 constexpr int kMaxMerged = 1024;  // S + n_importance <= 1024
 
+// Per-wave LDS working set, sized by the instantiation: the common configurations (S <= 64 coarse samples,
+// S + n_importance <= 256: 64+128, 64+64) need 2.5 KB per wave instead of the general 11 KB, which lifts the
+// occupancy of this latency-bound kernel from 3 to 4 waves per SIMD (then register-limited).
+template <int MAXB, int MAXM>
 struct FineSmem {
-    float bins[kMaxBins];
-    float cdf[kMaxBins];
-    float w[kMaxBins];
-    float zs[kMaxMerged];      // new samples
-    float merged[kMaxMerged];  // sort buffer / staging
+    float bins[MAXB];
+    float cdf[MAXB];
+    float w[MAXB];
+    float zs[MAXM];      // new samples
+    float merged[MAXM];  // sort buffer / staging (a power of two >= S + n_importance)
 };
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -84,14 +88,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // One wave per ray.  mode_fine: bins/weights are derived from (z_vals, full weights) as render.py:219-220
 // does; otherwise `zin` IS bins [nb] and `win` IS weights [nb-1] (plain sample_pdf).
+template <int MAXB, int MAXM>
 __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restrict__ zin,
                                                           const float *__restrict__ win, int64_t N, int S, int ns,
                                                           int mode_fine, const float *__restrict__ u_in,
                                                           float *__restrict__ z_samples,
                                                           float *__restrict__ z_merged, float *__restrict__ z_std) {
-    __shared__ FineSmem sm[4];
+    __shared__ FineSmem<MAXB, MAXM> sm[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    FineSmem &m = sm[wave];
+    FineSmem<MAXB, MAXM> &m = sm[wave];
     const int nb = mode_fine ? S - 1 : S;  // number of bins
     const int nw = nb - 1;                 // number of pdf weights
     const int zrow = mode_fine ? S : nb;   // row length of zin
@@ -428,8 +433,13 @@ extern "C" int nrf_sample_fine(const float *z_vals, const float *weights, int64_
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_fine: N_samples-1 <= %d and N_samples+N_importance <= %d",
                          kMaxBins, kMaxMerged);
     if (n_rays == 0) return NRF_OK;
-    hipLaunchKernelGGL(sample_fine_kernel, dim3(nrf::grid_for(n_rays, 4)), dim3(256), 0, nrf::as_stream(stream),
-                       z_vals, weights, n_rays, n_samples, n_importance, 1, u, z_samples, z_merged, z_std);
+    if (n_samples - 1 <= 64 && n_samples + n_importance <= 256)
+        hipLaunchKernelGGL((sample_fine_kernel<64, 256>), dim3(nrf::grid_for(n_rays, 4)), dim3(256), 0, nrf::as_stream(stream),
+                           z_vals, weights, n_rays, n_samples, n_importance, 1, u, z_samples, z_merged, z_std);
+    else
+        hipLaunchKernelGGL((sample_fine_kernel<kMaxBins, kMaxMerged>), dim3(nrf::grid_for(n_rays, 4)), dim3(256), 0,
+                           nrf::as_stream(stream), z_vals, weights, n_rays, n_samples, n_importance, 1, u, z_samples,
+                           z_merged, z_std);
     return nrf::check_launch("nrf_sample_fine");
 }
 
@@ -440,7 +450,12 @@ extern "C" int nrf_sample_pdf(const float *bins, const float *weights, int64_t n
     if (n_bins > kMaxBins || n_samples > kMaxMerged)
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_pdf: n_bins <= %d, n_samples <= %d", kMaxBins, kMaxMerged);
     if (n_rows == 0) return NRF_OK;
-    hipLaunchKernelGGL(sample_fine_kernel, dim3(nrf::grid_for(n_rows, 4)), dim3(256), 0, nrf::as_stream(stream),
-                       bins, weights, n_rows, n_bins, n_samples, 0, u, samples, (float *)nullptr, (float *)nullptr);
+    if (n_bins <= 64 && n_samples <= 256)
+        hipLaunchKernelGGL((sample_fine_kernel<64, 256>), dim3(nrf::grid_for(n_rows, 4)), dim3(256), 0, nrf::as_stream(stream),
+                           bins, weights, n_rows, n_bins, n_samples, 0, u, samples, (float *)nullptr, (float *)nullptr);
+    else
+        hipLaunchKernelGGL((sample_fine_kernel<kMaxBins, kMaxMerged>), dim3(nrf::grid_for(n_rows, 4)), dim3(256), 0,
+                           nrf::as_stream(stream), bins, weights, n_rows, n_bins, n_samples, 0, u, samples,
+                           (float *)nullptr, (float *)nullptr);
     return nrf::check_launch("nrf_sample_pdf");
 }
