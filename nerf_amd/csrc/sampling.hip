@@ -88,6 +88,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // One wave per ray.  mode_fine: bins/weights are derived from (z_vals, full weights) as render.py:219-220
 // does; otherwise `zin` IS bins [nb] and `win` IS weights [nb-1] (plain sample_pdf).
+// The waves of a block never share data: a wave's LDS accesses execute in order, so lanes only need the compiler not
+// to move LDS accesses across the hand-over points.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int MAXB, int MAXM>
 __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restrict__ zin,
                                                           const float *__restrict__ win, int64_t N, int S, int ns,
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
             for (int i = lane; i < nw; i += 64)
                 m.w[i] = __fadd_rn(mode_fine ? wt[i + 1] : wt[i], 1e-5f);                    // sampling.py:19
         }
-        __syncthreads();
+        wsync();
         float s = 0.0f;
         if (live) {
             // sampling.py:20 torch.sum(weights, -1): ATen vectorized_inner_sum order (8 lanes x ILP 4).
@@ -150,7 +157,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
             }
             if (lane == 0) m.cdf[0] = 0.0f;
         }
-        __syncthreads();
+        wsync();
         bool sorted_ok = true;
         double sum1 = 0.0;
         if (live) {
@@ -183,7 +190,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
             }
             sorted_ok = __all(sorted_ok);
         }
-        __syncthreads();
+        wsync();
         if (live && z_std) {  // render.py:238 torch.std(z_samples, unbiased=False); tolerance-level
             double mean = wave_sum_f64(sum1) / (double)ns;
             double v = 0.0;
@@ -219,34 +226,29 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
                     out[j + lo] = v;
                 }
             }
-            // slow path (any wave of the block may need it -> block-uniform control flow for the barriers)
-            int need_sort = __syncthreads_or(live && !fast);
-            if (need_sort) {
+            // slow path: bitonic sort of the wave's own array
+            if (live && !fast) {   // wave-uniform: every wave works on its own LDS arrays, no block-level coupling
                 int T2 = 1;
                 while (T2 < total) T2 <<= 1;
-                if (live && !fast) {
-                    for (int i = lane; i < T2; i += 64)
-                        m.merged[i] = (i < S) ? z[i] : (i < total ? m.zs[i - S] : INFINITY);
-                }
-                __syncthreads();
+                for (int i = lane; i < T2; i += 64)
+                    m.merged[i] = (i < S) ? z[i] : (i < total ? m.zs[i - S] : INFINITY);
+                wsync();
                 for (int k = 2; k <= T2; k <<= 1)
                     for (int j = k >> 1; j > 0; j >>= 1) {
-                        if (live && !fast)
-                            for (int i = lane; i < T2; i += 64) {
-                                int p = i ^ j;
-                                if (p > i) {
-                                    float a = m.merged[i], b = m.merged[p];
-                                    bool up = (i & k) == 0;
-                                    if ((a > b) == up) { m.merged[i] = b; m.merged[p] = a; }
-                                }
+                        for (int i = lane; i < T2; i += 64) {
+                            int p = i ^ j;
+                            if (p > i) {
+                                float a = m.merged[i], b = m.merged[p];
+                                bool up = (i & k) == 0;
+                                if ((a > b) == up) { m.merged[i] = b; m.merged[p] = a; }
                             }
-                        __syncthreads();
+                        }
+                        wsync();
                     }
-                if (live && !fast)
-                    for (int i = lane; i < total; i += 64) z_merged[r * total + i] = m.merged[i];
+                for (int i = lane; i < total; i += 64) z_merged[r * total + i] = m.merged[i];
             }
         }
-        __syncthreads();
+        wsync();
     }
 }
 
