@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
                 m.bins[i] = mode_fine ? __fmul_rn(0.5f, __fadd_rn(z[i + 1], z[i])) : z[i];   // render.py:219
             for (int i = lane; i < nw; i += 64)
                 m.w[i] = __fadd_rn(mode_fine ? wt[i + 1] : wt[i], 1e-5f);                    // sampling.py:19
+            if (mode_fine && z_merged)   // the merge's binary searches run over LDS, not over global memory
+                for (int i = lane; i < S; i += 64) m.merged[i] = z[i];
         }
         wsync();
         float s = 0.0f;
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
             bool zsorted = true;
             if (live) {
                 for (int i = lane; i + 1 < S; i += 64)
-                    if (z[i + 1] < z[i]) zsorted = false;
+                    if (m.merged[i + 1] < m.merged[i]) zsorted = false;
                 zsorted = __all(zsorted);
             }
             const bool fast = live && sorted_ok && zsorted;  // wave-uniform
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
                 // rank-merge of two sorted lists: rank(z[i]) = i + #{zs < z[i]}, rank(zs[j]) = j + #{z <= zs[j]}
                 float *out = z_merged + r * total;
                 for (int i = lane; i < S; i += 64) {
-                    float v = z[i];
+                    float v = m.merged[i];
                     int lo = 0, hi = ns;
                     while (lo < hi) { int mid = (lo + hi) >> 1; if (m.zs[mid] < v) lo = mid + 1; else hi = mid; }
                     out[i + lo] = v;
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
                 for (int j = lane; j < ns; j += 64) {
                     float v = m.zs[j];
                     int lo = 0, hi = S;
-                    while (lo < hi) { int mid = (lo + hi) >> 1; if (z[mid] <= v) lo = mid + 1; else hi = mid; }
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if (m.merged[mid] <= v) lo = mid + 1; else hi = mid; }
                     out[j + lo] = v;
                 }
             }
