@@ -53,6 +53,29 @@ __global__ void __launch_bounds__(256) sample_coarse_kernel(const float *__restr
     }
 }
 
+// Four consecutive samples of one ray per thread (S % 4 == 0, 16-byte aligned rows): one 16-byte load of depths,
+// three 16-byte stores, no per-element 64-bit divisions -- the same two rounded operations per value.
+__global__ void __launch_bounds__(256) points4_kernel(const float *__restrict__ rays, int64_t n_quads, int ncol, int S4,
+                                                      const float4 *__restrict__ z4, float4 *__restrict__ pts4) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = n_quads < (1ll << 31) ? (int64_t)((uint32_t)q / (uint32_t)S4) : q / S4;
+        const float *ray = rays + r * ncol;
+        const float o0 = ray[0], o1 = ray[1], o2 = ray[2], d0 = ray[3], d1 = ray[4], d2 = ray[5];
+        const float4 z = z4[q];
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+        float p[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p[3 * k + 0] = __fadd_rn(o0, __fmul_rn(d0, zz[k]));      // render.py:210: separate mul and add
+            p[3 * k + 1] = __fadd_rn(o1, __fmul_rn(d1, zz[k]));
+            p[3 * k + 2] = __fadd_rn(o2, __fmul_rn(d2, zz[k]));
+        }
+        pts4[3 * q + 0] = make_float4(p[0], p[1], p[2], p[3]);
+        pts4[3 * q + 1] = make_float4(p[4], p[5], p[6], p[7]);
+        pts4[3 * q + 2] = make_float4(p[8], p[9], p[10], p[11]);
+    }
+}
+
 __global__ void __launch_bounds__(256) points_kernel(const float *__restrict__ rays, int64_t total, int ncol, int S,
                                                      const float *__restrict__ z_vals, float *__restrict__ pts) {
     // one thread per output float: pts[(r*S+i)*3+c] = o[c] + d[c]*z  (render.py:210: separate mul and add)
@@ -423,6 +446,13 @@ extern "C" int nrf_points(const float *rays, int64_t n_rays, int32_t ncol, const
     NRF_REQUIRE(n_rays >= 0 && ncol >= 6 && n_samples >= 1, "nrf_points: bad sizes");
     if (n_rays == 0) return NRF_OK;
     int64_t total = n_rays * n_samples * 3;
+    if (n_samples % 4 == 0 && ((uintptr_t)z_vals & 15) == 0 && ((uintptr_t)pts & 15) == 0) {
+        const int64_t n_quads = n_rays * (n_samples / 4);
+        hipLaunchKernelGGL(points4_kernel, dim3(nrf::grid_for(n_quads, 256, 256 * 32)), dim3(256), 0, nrf::as_stream(stream),
+                           rays, n_quads, ncol, n_samples / 4, reinterpret_cast<const float4 *>(z_vals),
+                           reinterpret_cast<float4 *>(pts));
+        return nrf::check_launch("nrf_points");
+    }
     hipLaunchKernelGGL(points_kernel, dim3(nrf::grid_for(total, 256)), dim3(256), 0, nrf::as_stream(stream), rays,
                        total, ncol, n_samples, z_vals, pts);
     return nrf::check_launch("nrf_points");
