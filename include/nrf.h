@@ -174,6 +174,15 @@ int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const 
                        const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                        void *stream);
 
+/* ---- bf16x3: the same query at f32-grade accuracy on the bf16 matrix pipe (no counterpart in the reference).
+ * Every f32 operand is carried as hi = bf16(v), lo = bf16(v - hi); a product is the three MFMAs Wh*xh + Wh*xl + Wl*xh
+ * accumulated in f32.  Raw outputs agree with the f32 kernel to ~1e-5 of their scale (bf16: 5e-3), rendered values to the
+ * f32 bar of 1e-4; about 3x the f32-MFMA kernel's rate.  `packed` = nrf_mlp_bf16x3_packed_bytes() bytes.  Inference only. */
+int64_t nrf_mlp_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_mlp_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
+int nrf_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                         const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
+
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */
 int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb);

@@ -67,7 +67,8 @@ struct BfBlock { int32_t type, param, ksteps, col0, ncols; };
 struct BfLayer {
     const float *W, *b;
     int32_t ld, n_out, nt_out, nblk;
-    int32_t tail, pad_;   // the last `tail` k-steps are stored tile-outer ([out tile][k-step]), the rest [k-step][out tile]
+    int32_t tail;    // the last `tail` k-steps are stored tile-outer ([out tile][k-step]), the rest [k-step][out tile]
+    int32_t split;   // bf16x3: every fragment is followed by its residual fragment, lo = bf16(w - float(bf16(w)))
     BfBlock blk[3];
     int64_t dst;   // byte offset in the stream
 };
@@ -76,9 +77,10 @@ struct BfLayer {
 __global__ void pack_bf16_kernel(BfLayer a, char *stream) {
     int ks_total = 0;
     for (int i = 0; i < a.nblk; ++i) ks_total += a.blk[i].ksteps;
-    const int64_t nthreads = (int64_t)ks_total * a.nt_out * 64;
+    const int64_t nthreads = (int64_t)ks_total * a.nt_out * 64 * (a.split ? 2 : 1);
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < nthreads; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int lane = idx & 63, frag = (int)(idx >> 6);
+        const int lane = idx & 63, sfrag = (int)(idx >> 6);          // fragment index in the stream
+        const int frag = a.split ? sfrag >> 1 : sfrag, lo_part = a.split ? sfrag & 1 : 0;
         const int head = (ks_total - a.tail) * a.nt_out;
         int t, s;
         if (frag < head) { t = frag % a.nt_out; s = frag / a.nt_out; }
@@ -101,9 +103,10 @@ __global__ void pack_bf16_kernel(BfLayer a, char *stream) {
                 if (ch >= 0 && ch < B.ncols) w = a.W[(int64_t)out * a.ld + B.col0 + ch];
                 else if (ch == -2) w = a.b[out];
             }
-            v[j] = (__bf16)w;
+            const __bf16 hi = (__bf16)w;
+            v[j] = lo_part ? (__bf16)(w - (float)hi) : hi;
         }
-        *reinterpret_cast<bf16x8 *>(stream + a.dst + (int64_t)frag * kFrag + lane * 16) = v;
+        *reinterpret_cast<bf16x8 *>(stream + a.dst + (int64_t)sfrag * kFrag + lane * 16) = v;
     }
 }
 
@@ -116,15 +119,16 @@ struct BfPlan {
     BfLayer layer[2 * NRF_MAX_D + 12];
     BfBiasEntry bias[8];
     int n = 0, nbias = 0;
+    int split = 0;      // bf16x3 stream: hi and residual fragments interleaved
     int64_t bytes = 0;
     void add(const float *W, const float *b, int ld, int n_out, int nt_out, int tail, BfBlock b0, BfBlock b1 = {}, BfBlock b2 = {}) {
         BfLayer &L = layer[n++];
-        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out; L.tail = tail;
+        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out; L.tail = tail; L.split = split;
         L.blk[0] = b0; L.blk[1] = b1; L.blk[2] = b2;
         L.nblk = 1 + (b1.type != BFB_NONE) + (b2.type != BFB_NONE);
         L.dst = bytes;
         int64_t ks = b0.ksteps + b1.ksteps + b2.ksteps;
-        bytes += (ks * nt_out * kFrag + kChunk - 1) / kChunk * kChunk;
+        bytes += (ks * nt_out * (split ? 2 : 1) * kFrag + kChunk - 1) / kChunk * kChunk;
     }
     void add_bias(const float *src, int n_, int dst) { bias[nbias++] = BfBiasEntry{src, n_, dst}; }
 };
@@ -281,13 +285,13 @@ struct WStream {
     }
 };
 
-// acc[p][t] (+)= W_layer * B(p, s) over the layer's S k-steps; B(p, s) = 8 bf16 of point tile p for k-step s.
-// The layer's N = S * NT_OUT fragments start on a chunk boundary; N % kAhead == 0 keeps q's phase static.
-template <int NT_OUT, int S, class BF>
-__device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st, BF &&B) {
-    constexpr int N = S * NT_OUT;
+// The N fragments of a layer, in stream order: body(i, a) gets fragment i between two scheduling barriers; around it
+// the chunk protocol runs -- publish the next chunk mid-chunk, copy requests spread over the following fragment slots,
+// LDS reads kAhead fragments ahead across chunk and layer boundaries.  The layer starts on a chunk boundary;
+// N % kAhead == 0 keeps q's phase static.
+template <int N, class Body>
+__device__ __forceinline__ void stream_frags(WStream &st, Body &&body) {
     static_assert(N % kAhead == 0 && N >= kAhead, "fragment count of a layer must be a multiple of the read-ahead");
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int NCH = (N + 15) / 16;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -312,13 +316,38 @@ __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st
                 else st.q[i % kAhead] = st.read(true, j - N);          // the next layer's first fragments
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int s = i / NT_OUT, t = i % NT_OUT;
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(0, s), s == 0 ? zero : acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(1, s), s == 0 ? zero : acc[1][t], 0, 0, 0);
+            body(i, a);
             __builtin_amdgcn_sched_barrier(0);
         }
         st.rotate();
     }
+}
+
+// acc[p][t] (+)= W_layer * B(p, s) over the layer's S k-steps; B(p, s) = 8 bf16 of point tile p for k-step s.
+template <int NT_OUT, int S, class BF>
+__device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st, BF &&B) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    stream_frags<S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
+        const int s = i / NT_OUT, t = i % NT_OUT;
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(0, s), s == 0 ? zero : acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(1, s), s == 0 ? zero : acc[1][t], 0, 0, 0);
+    });
+}
+
+// bf16x3: acc[t] (+)= W * x with W = Wh + Wl, x = xh + xl (bf16 each) as Wh*xh + Wh*xl + Wl*xh.  The stream holds
+// (hi, residual) fragment pairs; one 32-point tile per wave; all three MFMAs of a pair accumulate into the same tile.
+template <int NT_OUT, int S, class BH, class BL>
+__device__ __forceinline__ void gemm_layer_x3(f32x16 (&acc)[NT_OUT], WStream &st, BH &&Bh, BL &&Bl) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    stream_frags<2 * S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
+        const int j = i >> 1, s = j / NT_OUT, t = j % NT_OUT;
+        if ((i & 1) == 0) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bh(s), s == 0 ? zero : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bl(s), acc[t], 0, 0, 0);
+        } else {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bh(s), acc[t], 0, 0, 0);
+        }
+    });
 }
 
 // accumulators -> next layer's B fragments: k-step 2t+e = registers 8e..8e+7 of tile t, packed pairwise
@@ -534,6 +563,145 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
         for (int i = 0; i < 8; ++i) atomicAdd(&a.prof_out[i], (unsigned long long)prof[i]);
     }
 #endif
+}
+
+// ---- bf16x3: f32-grade accuracy from the bf16 matrix pipe ------------------------------------------------
+// Every f32 operand v is carried as hi = bf16(v) and lo = bf16(v - hi): 16 mantissa bits.  A product W*x is the three
+// MFMAs Wh*xh + Wh*xl + Wl*xh accumulated in f32 (the dropped Wl*xl is 2^-18 relative).  Measured against the f32
+// reference the raw outputs differ by ~1e-5 of their scale (bf16 alone: 5e-3), i.e. the f32 parity bar, at a third of the
+// bf16 kernel's point rate -- still ~3x the f32-MFMA kernel, whose matrix rate equals the vector rate on this chip.
+// One 32-point tile per wave (the accumulators are shared by the three products), four waves per workgroup.
+__device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+    hi = pack2(a, b);
+    lo = pack2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
+template <int NT>
+__device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&acc)[NT], bool relu) {
+    const float lo_bound = relu ? 0.0f : -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r[k]) : "a"(acc[t][k]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r[k] = fmaxf(r[k], lo_bound);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t hi, lo;
+            split2(r[2 * w], r[2 * w + 1], hi, lo);
+            hh[2 * t + (w >> 2)][w & 3] = hi;
+            hl[2 * t + (w >> 2)][w & 3] = lo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// gamma(v) of a 3-vector (slot order of bf_pe3_chan), every frequency by an accurate sincosf: the recurrence of
+// fill_pe3_bf16 is only good to ~2^-16
+template <int KS>
+__device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], float x, float y, float z, int h) {
+    constexpr int NF = (8 * KS - 2) / 6;
+    float v[8 * KS];
+    v[0] = h ? z : x;
+    v[1] = h ? 1.0f : y;
+    const float co[3] = {x, y, z};
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const float sc = pow2i(2 * i + h);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sincosf(co[d] * sc, &v[2 + 6 * i + d], &v[2 + 6 * i + 3 + d]);
+    }
+#pragma unroll
+    for (int i = 2 + 6 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t hi, lo;
+            split2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1], hi, lo);
+            oh[k][w] = hi;
+            ol[k][w] = lo;
+        }
+}
+
+template <int NT, bool VIEWS>
+__global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args a) {
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    WStream st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
+    st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.start();
+    const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
+    const int64_t ntiles = (a.n_points + 127) >> 7;
+    u32x4v one, none;   // the constant-1 channel of a bias k-step (element 0 of lane half 0) and its zero residual
+    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+    none[0] = 0; none[1] = 0; none[2] = 0; none[3] = 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pp = tile * 128 + st.wave * 32 + n;
+        const int64_t pc = pp < a.n_points ? pp : a.n_points - 1;
+        u32x4v xh[kBfKsX], xl[kBfKsX];
+        u32x4v dh[VIEWS ? kBfKsD : 1], dl[VIEWS ? kBfKsD : 1];
+        {
+            const float *q = a.pts + pc * 3;
+            if constexpr (VIEWS) {
+                const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
+                fill_pe3_x3<kBfKsD>(dh, dl, d[0], d[1], d[2], h);
+            }
+            fill_pe3_x3<kBfKsX>(xh, xl, q[0], q[1], q[2], h);
+        }
+        f32x16 acc[NT];
+        u32x4v hh[2 * NT], hl[2 * NT];
+        auto Hh = [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); };
+        auto Hl = [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); };
+        // trunk (network.py:48-53)
+        gemm_layer_x3<NT, kBfKsX>(acc, st, [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); });
+        pack_acts_x3<NT>(hh, hl, acc, true);
+        for (int l = 1; l < a.n_trunk; ++l) {
+            if ((a.skip_in_mask >> l) & 1)
+                gemm_layer_x3<NT, kBfKsX + 2 * NT>(
+                    acc, st,
+                    [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(hh[s >= kBfKsX ? s - kBfKsX : 0]); },
+                    [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(hl[s >= kBfKsX ? s - kBfKsX : 0]); });
+            else
+                gemm_layer_x3<NT, 2 * NT + 1>(acc, st, Hh, Hl);
+            pack_acts_x3<NT>(hh, hl, acc, true);
+        }
+        if constexpr (VIEWS) {
+            f32x16 acc1[1];
+            gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:56
+            const float alpha = acc1[0][0] + hb[kHbAlpha];
+            gemm_layer_x3<NT, 2 * NT + 1>(acc, st, Hh, Hl);                                          // network.py:57
+            pack_acts_x3<NT>(hh, hl, acc, false);
+            f32x16 acc2[NT / 2];
+            gemm_layer_x3<NT / 2, 2 * NT + kBfKsD>(                                                  // network.py:58-62
+                acc2, st,
+                [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(dh[s >= 2 * NT ? s - 2 * NT : 0]); },
+                [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(dl[s >= 2 * NT ? s - 2 * NT : 0]); });
+            u32x4v vh[NT], vl[NT];
+            pack_acts_x3<NT / 2>(vh, vl, acc2, true);
+            gemm_layer_x3<1, NT>(acc1, st, [&](int s) { return as_bf(vh[s]); }, [&](int s) { return as_bf(vl[s]); });     // network.py:64
+            if (h == 0 && pp < a.n_points)
+                reinterpret_cast<float4 *>(a.raw)[pp] = make_float4(acc1[0][0] + hb[kHbRgb], acc1[0][1] + hb[kHbRgb + 1],
+                                                                    acc1[0][2] + hb[kHbRgb + 2], alpha);
+        } else {
+            f32x16 acc1[1];
+            gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:67
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * h + r;   // rows 0-3 on lane half 0, 4-7 on half 1 (registers 0..3)
+                if (o < a.output_ch && pp < a.n_points) a.raw[pp * a.output_ch + o] = acc1[0][r] + hb[kHbOut + o];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests in flight must land before the LDS is released
+    __builtin_amdgcn_s_barrier();
 }
 
 // gamma(t) of a scalar into KS k-step fragments (slot order of bf_pe1_chan)
@@ -773,6 +941,66 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
             break;
     }
     return check_launch("nrf_query_fwd_bf16");
+}
+
+extern "C" int64_t nrf_mlp_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+    if (!net || !emb) return -1;
+    if (const char *e = bf_check_net(net, emb, false)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16x3_packed_bytes: %s", e); return -1; }
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net(P, net, emb, false);
+    return bf_total_bytes(P);
+}
+
+extern "C" int nrf_mlp_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    NRF_REQUIRE(net && emb && packed, "nrf_mlp_bf16x3_pack_weights: null pointer");
+    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16x3_pack_weights: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nrf_mlp_bf16x3_pack_weights: packed must be 16-byte aligned");
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net(P, net, emb, false);
+    return bf_pack(P, packed, as_stream(stream));
+}
+
+extern "C" int nrf_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                    const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
+    NRF_REQUIRE(net && emb, "nrf_query_fwd_bf16x3: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd_bf16x3: null pointer");
+    NRF_REQUIRE(n_points >= 0, "nrf_query_fwd_bf16x3: negative n_points");
+    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd_bf16x3: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
+                "nrf_query_fwd_bf16x3: packed and raw must be 16-byte aligned");
+    if (net->use_viewdirs && n_points != 0) {
+        NRF_REQUIRE(viewdirs, "nrf_query_fwd_bf16x3: viewdirs is null but the net uses view directions");
+        NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0,
+                    "nrf_query_fwd_bf16x3: n_points (%lld) must be a multiple of pts_per_ray (%d)", (long long)n_points, pts_per_ray);
+    }
+    if (n_points == 0) return NRF_OK;
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net(P, net, emb, false);
+    Bf16Args a{};
+    a.stream = (const char *)packed; a.stream_bytes = P.bytes;
+    a.pts = pts; a.viewdirs = viewdirs; a.raw = raw; a.n_points = n_points;
+    a.pts_per_ray = pts_per_ray > 0 ? pts_per_ray : 1;
+    a.n_trunk = net->D;
+    a.skip_in_mask = 0;
+    for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
+    a.use_viewdirs = net->use_viewdirs; a.output_ch = net->output_ch;
+    const int64_t ntiles = (n_points + 127) / 128;
+    const int blocks = (int)(ntiles < 256 ? ntiles : 256);
+    hipStream_t st = as_stream(stream);
+    switch (net->W / 32) {
+        case 8:
+            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a);
+            break;
+        case 4:
+            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a);
+            break;
+    }
+    return check_launch("nrf_query_fwd_bf16x3");
 }
 
 #ifdef NRF_BF16_PROFILE

@@ -62,8 +62,10 @@ class NeRF(nn.Module):
         else:
             self.output_linear = nn.Linear(W, output_ch)
         self._packed_cache = {}
-        # "fp32" (exact f32 MFMA, the reference's arithmetic) or "bf16" (bf16 MFMA, f32 accumulate; inference
-        # through render()'s fused query only).  Not part of the reference's constructor: set as an attribute.
+        # "fp32" (exact f32 MFMA, the reference's arithmetic), "bf16" (bf16 MFMA, f32 accumulate) or "bf16x3" (every
+        # product as three bf16 MFMAs on hi/residual operands: f32-grade accuracy at ~3x the f32 kernel's rate); the
+        # two bf16 modes serve inference through render()'s fused query only.  Not part of the reference's constructor:
+        # set as an attribute.
         self.precision = "fp32"
 
     # ------------------------------------------------------------------ packed weights
@@ -73,9 +75,10 @@ class NeRF(nn.Module):
         if pk is None:
             params = self._pack_params()
             mode, L, Lv = key[:3]
-            if len(key) > 3 and key[3] == "bf16":
-                pk = ops.PackedNetBf16(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
-                                       list(self.skips), self.use_viewdirs, multires=L, multires_views=Lv)
+            if len(key) > 3 and key[3] in ("bf16", "bf16x3"):
+                cls = ops.PackedNetBf16 if key[3] == "bf16" else ops.PackedNetBf16x3
+                pk = cls(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
+                         list(self.skips), self.use_viewdirs, multires=L, multires_views=Lv)
             else:
                 pk = ops.PackedNet(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
                                    list(self.skips), self.use_viewdirs, mode=mode, multires=L, multires_views=Lv)
@@ -115,8 +118,10 @@ class NeRF(nn.Module):
         """pts [P,3]; viewdirs [P/pts_per_ray, 3] or None -> raw [P, 4|output_ch] (render.py:31-56 fused)."""
         key = (0, multires, multires_views if self.use_viewdirs else 0)
         need_grad = self._need_grad(pts)
-        if self.precision == "bf16" and not need_grad:   # inference only; training stays exact f32
-            key = key + ("bf16",)
+        if self.precision in ("bf16", "bf16x3") and not need_grad:   # inference only; training stays exact f32
+            key = key + (self.precision,)
+        elif self.precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError(f"precision must be 'fp32', 'bf16' or 'bf16x3', not {self.precision!r}")
         return _QueryFunction.apply(self, key, pts, viewdirs if self.use_viewdirs else None, pts_per_ray,
                                     need_grad, *self._params_in_order())
 

@@ -400,3 +400,48 @@ class PackedNetBf16(PackedNet):
 
     def query_train(self, *a, **k):
         raise NotImplementedError("the bf16 path is inference only; training runs on the f32 kernels")
+
+
+class PackedNetBf16x3(PackedNetBf16):
+    """bf16x3 weight stream (hi + residual fragments) for nrf_query_fwd_bf16x3: f32-grade accuracy on the bf16 matrix
+    pipe, about three times the f32 kernel's rate.  Inference only."""
+
+    def __init__(self, params, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, multires=0,
+                 multires_views=0):
+        self.params = params
+        self.net = NrfNet()
+        n = self.net
+        n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch = D, W, input_ch, input_ch_views, output_ch
+        n.use_viewdirs = int(bool(use_viewdirs))
+        n.skips_mask = sum(1 << int(s) for s in skips)
+        self.emb = NrfEmbed(0, multires, multires_views, 0)
+        self.n_bytes = _lib.lib().nrf_mlp_bf16x3_packed_bytes(C.byref(n), C.byref(self.emb))
+        if self.n_bytes <= 0:
+            raise RuntimeError("nrf_mlp_bf16x3_packed_bytes: " + _lib.lib().nrf_last_error_string().decode())
+        self.packed = None
+        self._versions = None
+        self.out_ch = 4 if use_viewdirs else output_ch
+
+    def refresh(self):
+        vers = tuple((v.data_ptr(), v._version) for v in self.params.values())
+        if self.packed is not None and vers == self._versions:
+            return
+        self._fill_pointers()
+        dev = next(iter(self._p.values())).device
+        if self.packed is None or self.packed.device != dev:
+            self.packed = torch.empty((self.n_bytes,), device=dev, dtype=torch.uint8)
+        check(_lib.lib().nrf_mlp_bf16x3_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()),
+              "nrf_mlp_bf16x3_pack_weights")
+        self._versions = vers
+
+    def query(self, pts, viewdirs=None, pts_per_ray=1):
+        self.refresh()
+        pts = _f32(pts, "pts")
+        P = pts.shape[0]
+        raw = torch.empty((P, self.out_ch), device=pts.device, dtype=torch.float32)
+        if viewdirs is not None:
+            viewdirs = _f32(viewdirs, "viewdirs")
+        check(_lib.lib().nrf_query_fwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                              _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _stream()),
+              "nrf_query_fwd_bf16x3")
+        return raw
