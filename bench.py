@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- rays/sec of the NeRF per-ray rendering path at 64 coarse + 128 fine samples per ray.
 
-    python bench.py --gpus N --steps K --warmup W [--workload render|fern|train|dnerf] [--precision fp32|bf16] [--size 800]
+    python bench.py --gpus N --steps K --warmup W [--workload render|fern|train|dnerf] [--precision fp32|bf16|bf16x3] [--size 800]
 
 A step = one full render of a synthetic 800x800 view (BASELINE.json configs[1]: D=8/W=256 coarse+fine
 nets, multires 10/4, view directions, white background, near/far 2/6, chunk 32768, perturb=0) through
@@ -198,7 +198,7 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
     a.steps, a.warmup = 10, 3
     also["train_step"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
     a.steps, a.warmup = 2, 1
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "bf16x3"):
         a.precision = prec
         also[f"dnerf_{prec}"] = brief(bench_dnerf.run_dnerf(a, torch, dist, 1, 0, device, emit=False))
     also["dnerf_train_step"] = bench_dnerf.run_dnerf_train(a, torch, device)

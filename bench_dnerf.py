@@ -29,8 +29,9 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
     model = model.to(device)
     model.embed_fn = embed_fn
     model.precision = args.precision
-    bf16 = args.precision == "bf16"
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    bf16, x3 = args.precision == "bf16", args.precision == "bf16x3"
+    # bf16x3 issues three bf16 MFMAs per f32 product: in f32-equivalent FLOP/s its roofline is a third of the bf16 peak
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 3 if x3 else PEAK_F32_MFMA_TFLOPS)
     qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
     kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
               white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
@@ -93,14 +94,15 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
             "metric": "rays/sec at 64+128 samples/ray (D-NeRF deformation render)",
             "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else ("bf16x3" if x3 else "f32"), "data": "synthetic",
             "config": {"workload": f"D-NeRF bouncingballs-shaped {H}x{W} view, deformation network (time net D=8 W=256 -> "
                                    f"dx -> canonical net D=8 W=256), 64+128 samples, one model for both passes, {args.precision}",
                        "rays_per_step": H * W,
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": ("dnerf_query_fwd_bf16_kernel<8>" if bf16 else "dnerf_query_fwd_kernel<8>")
+                         "kernel": ("dnerf_query_fwd_bf16_kernel<8>" if bf16 else
+                                    "dnerf_query_fwd_bf16x3_kernel<8>" if x3 else "dnerf_query_fwd_kernel<8>")
                          + " (gamma(x), gamma(t), time net, re-embed, canonical net)",
                          "launches": len(events), "avg_launch_ms": q_ms / max(len(events), 1),
                          "flop_per_point": FLOP_PER_POINT, "query_share_of_step": q_ms * 1e-3 / dt},

@@ -193,6 +193,17 @@ int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net_t *occ_net
                              int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
                              int32_t zero_canonical, float *raw, float *dx, void *stream);
 
+/* bf16x3 variant of K6: the deformation chain with every product as three bf16 MFMAs on hi/residual operands (see the
+ * bf16x3 block above); dx, x + dx and the re-embedding stay in f32.  Same arguments / results as nrf_dnerf_query_fwd_bf16;
+ * `packed` = nrf_dnerf_bf16x3_packed_bytes() bytes. */
+int64_t nrf_dnerf_bf16x3_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb);
+int nrf_dnerf_bf16x3_pack_weights(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                  void *packed, void *stream);
+int nrf_dnerf_query_fwd_bf16x3(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                               const void *packed, const float *pts, const float *viewdirs, const float *times,
+                               int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
+                               int32_t zero_canonical, float *raw, float *dx, void *stream);
+
 /* Fused optimizer step: torch.optim.Adam as model.py:52 / vanilla_dynamic/model.py:115 configure it
  * (no weight decay, no amsgrad), all tensors in one launch.  The pointer tables and `numel` are HOST arrays of
  * n_tensors entries holding DEVICE pointers; steps[i] is tensor i's 1-based step count (torch counts per parameter); grad_scale: NULL or a DEVICE scalar the

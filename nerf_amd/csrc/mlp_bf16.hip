@@ -626,6 +626,53 @@ __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
         }
 }
 
+// Trunk of one net in bf16x3: layer 0 on S0 encoded k-steps (B0h, B0l), then the hidden layers.
+template <int NT, int S0, class B0H, class B0L>
+__device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
+                                            const u32x4v (&xh)[kBfKsX], const u32x4v (&xl)[kBfKsX], const u32x4v &one,
+                                            const u32x4v &none, WStream &st, int n_trunk, int skip_in_mask, B0H &&b0h,
+                                            B0L &&b0l) {
+    gemm_layer_x3<NT, S0>(acc, st, b0h, b0l);
+    pack_acts_x3<NT>(hh, hl, acc, true);
+    for (int l = 1; l < n_trunk; ++l) {
+        if ((skip_in_mask >> l) & 1)
+            gemm_layer_x3<NT, kBfKsX + 2 * NT>(
+                acc, st,
+                [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(hh[s >= kBfKsX ? s - kBfKsX : 0]); },
+                [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(hl[s >= kBfKsX ? s - kBfKsX : 0]); });
+        else
+            gemm_layer_x3<NT, 2 * NT + 1>(
+                acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
+                [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });
+        pack_acts_x3<NT>(hh, hl, acc, true);
+    }
+}
+
+// View-direction head in bf16x3 (network.py:56-65) -> (rgb, alpha) of the wave's point tile, stored by lane half 0.
+template <int NT>
+__device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
+                                                 const u32x4v (&dh)[kBfKsD], const u32x4v (&dl)[kBfKsD], const u32x4v &one,
+                                                 const u32x4v &none, WStream &st, const float *hb, int64_t pp,
+                                                 int64_t n_points, int h, float *raw) {
+    f32x16 acc1[1];
+    gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });      // network.py:56
+    const float alpha = acc1[0][0] + hb[kHbAlpha];
+    gemm_layer_x3<NT, 2 * NT + 1>(acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
+                                  [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });   // network.py:57
+    pack_acts_x3<NT>(hh, hl, acc, false);
+    f32x16 acc2[NT / 2];
+    gemm_layer_x3<NT / 2, 2 * NT + kBfKsD>(                                                                          // network.py:58-62
+        acc2, st,
+        [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(dh[s >= 2 * NT ? s - 2 * NT : 0]); },
+        [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(dl[s >= 2 * NT ? s - 2 * NT : 0]); });
+    u32x4v vh[NT], vl[NT];
+    pack_acts_x3<NT / 2>(vh, vl, acc2, true);
+    gemm_layer_x3<1, NT>(acc1, st, [&](int s) { return as_bf(vh[s]); }, [&](int s) { return as_bf(vl[s]); });         // network.py:64
+    if (h == 0 && pp < n_points)
+        reinterpret_cast<float4 *>(raw)[pp] = make_float4(acc1[0][0] + hb[kHbRgb], acc1[0][1] + hb[kHbRgb + 1],
+                                                          acc1[0][2] + hb[kHbRgb + 2], alpha);
+}
+
 template <int NT, bool VIEWS>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
@@ -647,7 +694,7 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
         const int64_t pp = tile * 128 + st.wave * 32 + n;
         const int64_t pc = pp < a.n_points ? pp : a.n_points - 1;
         u32x4v xh[kBfKsX], xl[kBfKsX];
-        u32x4v dh[VIEWS ? kBfKsD : 1], dl[VIEWS ? kBfKsD : 1];
+        u32x4v dh[kBfKsD], dl[kBfKsD];
         {
             const float *q = a.pts + pc * 3;
             if constexpr (VIEWS) {
@@ -658,38 +705,10 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
         }
         f32x16 acc[NT];
         u32x4v hh[2 * NT], hl[2 * NT];
-        auto Hh = [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); };
-        auto Hl = [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); };
-        // trunk (network.py:48-53)
-        gemm_layer_x3<NT, kBfKsX>(acc, st, [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); });
-        pack_acts_x3<NT>(hh, hl, acc, true);
-        for (int l = 1; l < a.n_trunk; ++l) {
-            if ((a.skip_in_mask >> l) & 1)
-                gemm_layer_x3<NT, kBfKsX + 2 * NT>(
-                    acc, st,
-                    [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(hh[s >= kBfKsX ? s - kBfKsX : 0]); },
-                    [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(hl[s >= kBfKsX ? s - kBfKsX : 0]); });
-            else
-                gemm_layer_x3<NT, 2 * NT + 1>(acc, st, Hh, Hl);
-            pack_acts_x3<NT>(hh, hl, acc, true);
-        }
+        bf_trunk_x3<NT, kBfKsX>(acc, hh, hl, xh, xl, one, none, st, a.n_trunk, a.skip_in_mask,
+                                [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); });   // network.py:48-53
         if constexpr (VIEWS) {
-            f32x16 acc1[1];
-            gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:56
-            const float alpha = acc1[0][0] + hb[kHbAlpha];
-            gemm_layer_x3<NT, 2 * NT + 1>(acc, st, Hh, Hl);                                          // network.py:57
-            pack_acts_x3<NT>(hh, hl, acc, false);
-            f32x16 acc2[NT / 2];
-            gemm_layer_x3<NT / 2, 2 * NT + kBfKsD>(                                                  // network.py:58-62
-                acc2, st,
-                [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(dh[s >= 2 * NT ? s - 2 * NT : 0]); },
-                [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(dl[s >= 2 * NT ? s - 2 * NT : 0]); });
-            u32x4v vh[NT], vl[NT];
-            pack_acts_x3<NT / 2>(vh, vl, acc2, true);
-            gemm_layer_x3<1, NT>(acc1, st, [&](int s) { return as_bf(vh[s]); }, [&](int s) { return as_bf(vl[s]); });     // network.py:64
-            if (h == 0 && pp < a.n_points)
-                reinterpret_cast<float4 *>(a.raw)[pp] = make_float4(acc1[0][0] + hb[kHbRgb], acc1[0][1] + hb[kHbRgb + 1],
-                                                                    acc1[0][2] + hb[kHbRgb + 2], alpha);
+            bf_views_head_x3<NT>(acc, hh, hl, dh, dl, one, none, st, hb, pp, a.n_points, h, a.raw);
         } else {
             f32x16 acc1[1];
             gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:67
@@ -811,6 +830,88 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16_kernel(const Dner
     __builtin_amdgcn_s_barrier();
 }
 
+// gamma(t) of a scalar in bf16x3 (slot order of bf_pe1_chan), every frequency by an accurate sincosf
+template <int KS>
+__device__ __forceinline__ void fill_pe1_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], float t, int h) {
+    constexpr int NF = (8 * KS - 1) / 2;
+    float v[8 * KS];
+    v[0] = h ? 0.0f : t;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) sincosf(t * pow2i(2 * i + h), &v[1 + 2 * i], &v[2 + 2 * i]);
+#pragma unroll
+    for (int i = 1 + 2 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t hi, lo;
+            split2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1], hi, lo);
+            oh[k][w] = hi;
+            ol[k][w] = lo;
+        }
+}
+
+// K6 in bf16x3 (f32-grade accuracy): one 32-point tile per wave, otherwise the structure of dnerf_query_fwd_bf16_kernel.
+template <int NT>
+__global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16x3_kernel(const DnerfBf16Args a) {
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    WStream st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
+    st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.start();
+    const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
+    const int64_t ntiles = (a.n_points + 127) >> 7;
+    u32x4v one, none;
+    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+    none[0] = 0; none[1] = 0; none[2] = 0; none[3] = 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pp = tile * 128 + st.wave * 32 + n;
+        const int64_t pc = pp < a.n_points ? pp : a.n_points - 1;
+        float px[3], dv[3];
+        u32x4v xh[kBfKsX], xl[kBfKsX], th[kBfKsT], tl[kBfKsT], dh[kBfKsD], dl[kBfKsD];
+        const float *q = a.pts + pc * 3;
+        px[0] = q[0]; px[1] = q[1]; px[2] = q[2];
+        const int64_t chunk_first = (pc / a.netchunk) * a.netchunk;                 // network.py:315-322
+        const bool skip = a.zero_canonical && a.times[chunk_first / a.t_div] == 0.0f;
+        const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
+        dv[0] = d[0]; dv[1] = d[1]; dv[2] = d[2];
+        fill_pe3_x3<kBfKsX>(xh, xl, px[0], px[1], px[2], h);
+        fill_pe1_x3<kBfKsT>(th, tl, a.times[pc / a.t_div], h);
+        f32x16 acc[NT];
+        u32x4v hh[2 * NT], hl[2 * NT];
+        bf_trunk_x3<NT, kBfKsX + kBfKsT>(
+            acc, hh, hl, xh, xl, one, none, st, a.t_trunk, a.t_skip_mask,
+            [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(th[s >= kBfKsX ? s - kBfKsX : 0]); },
+            [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(tl[s >= kBfKsX ? s - kBfKsX : 0]); });
+        {
+            f32x16 acc1[1];
+            gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:305
+            float dd[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dd[k] = __shfl(acc1[0][k] + hb[kHbTime + k], n);   // rows 0..2 live in lane half 0; both halves encode
+                if (skip) dd[k] = 0.0f;
+                px[k] += dd[k];                                                                     // network.py:331
+            }
+            if (h == 0 && pp < a.n_points) {
+                a.dx[pp * 3 + 0] = dd[0]; a.dx[pp * 3 + 1] = dd[1]; a.dx[pp * 3 + 2] = dd[2];
+            }
+            fill_pe3_x3<kBfKsX>(xh, xl, px[0], px[1], px[2], h);                                    // network.py:332-333
+            fill_pe3_x3<kBfKsD>(dh, dl, dv[0], dv[1], dv[2], h);
+        }
+        bf_trunk_x3<NT, kBfKsX>(acc, hh, hl, xh, xl, one, none, st, a.c_trunk, a.c_skip_mask,
+                                [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); });
+        bf_views_head_x3<NT>(acc, hh, hl, dh, dl, one, none, st, hb, pp, a.n_points, h, a.raw);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -829,40 +930,45 @@ static const char *bf_check_dnerf(const nrf_net_t *time_net, const nrf_net_t *oc
     return nullptr;
 }
 
-extern "C" int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb) {
+// D-NeRF entry points, shared by the bf16 (split = 0) and bf16x3 (split = 1) variants
+static int64_t dnerf_packed_bytes_impl(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb, int split,
+                                       const char *who) {
     if (!time_net || !occ_net || !emb) return -1;
-    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_bf16_packed_bytes: %s", e); return -1; }
+    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) { nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e); return -1; }
     BfPlan P;
+    P.split = split;
     bf_plan_net(P, time_net, emb, true);
     bf_plan_net(P, occ_net, emb, false);
     return bf_total_bytes(P);
 }
 
-extern "C" int nrf_dnerf_bf16_pack_weights(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
-                                           void *packed, void *stream) {
-    NRF_REQUIRE(time_net && occ_net && emb && packed, "nrf_dnerf_bf16_pack_weights: null pointer");
-    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_bf16_pack_weights: %s", e);
-    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nrf_dnerf_bf16_pack_weights: packed must be 16-byte aligned");
+static int dnerf_pack_impl(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb, void *packed,
+                           void *stream, int split, const char *who) {
+    NRF_REQUIRE(time_net && occ_net && emb && packed, "%s: null pointer", who);
+    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "%s: packed must be 16-byte aligned", who);
     BfPlan P;
+    P.split = split;
     bf_plan_net(P, time_net, emb, true);
     bf_plan_net(P, occ_net, emb, false);
     return bf_pack(P, packed, as_stream(stream));
 }
 
-extern "C" int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
-                                        const void *packed, const float *pts, const float *viewdirs, const float *times,
-                                        int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
-                                        int32_t zero_canonical, float *raw, float *dx, void *stream) {
-    NRF_REQUIRE(time_net && occ_net && emb, "nrf_dnerf_query_fwd_bf16: null descriptor");
+static int dnerf_query_impl(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb, const void *packed,
+                            const float *pts, const float *viewdirs, const float *times, int64_t n_points,
+                            int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk, int32_t zero_canonical,
+                            float *raw, float *dx, void *stream, int split, const char *who) {
+    NRF_REQUIRE(time_net && occ_net && emb, "%s: null descriptor", who);
     if (n_points != 0) NRF_REQUIRE(time_net && occ_net && emb && packed && pts && viewdirs && times && raw && dx,
-                "nrf_dnerf_query_fwd_bf16: null pointer");
-    NRF_REQUIRE(n_points >= 0 && pts_per_ray >= 1 && netchunk >= 1, "nrf_dnerf_query_fwd_bf16: bad sizes");
-    NRF_REQUIRE(n_points % pts_per_ray == 0, "nrf_dnerf_query_fwd_bf16: n_points must be a multiple of pts_per_ray");
-    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_query_fwd_bf16: %s", e);
+                "%s: null pointer", who);
+    NRF_REQUIRE(n_points >= 0 && pts_per_ray >= 1 && netchunk >= 1, "%s: bad sizes", who);
+    NRF_REQUIRE(n_points % pts_per_ray == 0, "%s: n_points must be a multiple of pts_per_ray", who);
+    if (const char *e = bf_check_dnerf(time_net, occ_net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e);
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
-                "nrf_dnerf_query_fwd_bf16: packed and raw must be 16-byte aligned");
+                "%s: packed and raw must be 16-byte aligned", who);
     if (n_points == 0) return NRF_OK;
     BfPlan P;
+    P.split = split;
     bf_plan_net(P, time_net, emb, true);
     bf_plan_net(P, occ_net, emb, false);
     DnerfBf16Args a{};
@@ -872,14 +978,46 @@ extern "C" int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net
     a.t_div = times_per_point ? 1 : pts_per_ray; a.zero_canonical = zero_canonical;
     a.t_trunk = time_net->D; a.t_skip_mask = skip_in_mask_of(time_net);
     a.c_trunk = occ_net->D; a.c_skip_mask = skip_in_mask_of(occ_net);
-    const int64_t ntiles = (n_points + 255) / 256;
+    const int per_wg = split ? 128 : 256;            // points per workgroup pass
+    const int64_t ntiles = (n_points + per_wg - 1) / per_wg;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);
     hipStream_t st = as_stream(stream);
-    switch (occ_net->W / 32) {
+    switch (occ_net->W / 32 + (split ? 100 : 0)) {
         case 8: hipLaunchKernelGGL((dnerf_query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
         case 4: hipLaunchKernelGGL((dnerf_query_fwd_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 108: hipLaunchKernelGGL((dnerf_query_fwd_bf16x3_kernel<8>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 104: hipLaunchKernelGGL((dnerf_query_fwd_bf16x3_kernel<4>), dim3(blocks), dim3(256), 0, st, a); break;
     }
-    return check_launch("nrf_dnerf_query_fwd_bf16");
+    return check_launch(who);
+}
+
+extern "C" int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb) {
+    return dnerf_packed_bytes_impl(time_net, occ_net, emb, 0, "nrf_dnerf_bf16_packed_bytes");
+}
+extern "C" int nrf_dnerf_bf16_pack_weights(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                           void *packed, void *stream) {
+    return dnerf_pack_impl(time_net, occ_net, emb, packed, stream, 0, "nrf_dnerf_bf16_pack_weights");
+}
+extern "C" int nrf_dnerf_query_fwd_bf16(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                        const void *packed, const float *pts, const float *viewdirs, const float *times,
+                                        int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
+                                        int32_t zero_canonical, float *raw, float *dx, void *stream) {
+    return dnerf_query_impl(time_net, occ_net, emb, packed, pts, viewdirs, times, n_points, pts_per_ray, times_per_point,
+                            netchunk, zero_canonical, raw, dx, stream, 0, "nrf_dnerf_query_fwd_bf16");
+}
+extern "C" int64_t nrf_dnerf_bf16x3_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb) {
+    return dnerf_packed_bytes_impl(time_net, occ_net, emb, 1, "nrf_dnerf_bf16x3_packed_bytes");
+}
+extern "C" int nrf_dnerf_bf16x3_pack_weights(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                             void *packed, void *stream) {
+    return dnerf_pack_impl(time_net, occ_net, emb, packed, stream, 1, "nrf_dnerf_bf16x3_pack_weights");
+}
+extern "C" int nrf_dnerf_query_fwd_bf16x3(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,
+                                          const void *packed, const float *pts, const float *viewdirs, const float *times,
+                                          int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, int64_t netchunk,
+                                          int32_t zero_canonical, float *raw, float *dx, void *stream) {
+    return dnerf_query_impl(time_net, occ_net, emb, packed, pts, viewdirs, times, n_points, pts_per_ray, times_per_point,
+                            netchunk, zero_canonical, raw, dx, stream, 1, "nrf_dnerf_query_fwd_bf16x3");
 }
 
 extern "C" int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {

@@ -172,8 +172,9 @@ class DNeRF_Deformation(nn.Module):
         self._bf16_versions = None
         self._time_net = None
         self._time_net_key = None
-        # "fp32" (the reference's arithmetic) or "bf16" (bf16 MFMA, f32 accumulate, inference only); an attribute,
-        # not a constructor argument of the reference
+        # "fp32" (the reference's arithmetic), "bf16" (bf16 MFMA, f32 accumulate) or "bf16x3" (three bf16 MFMAs per
+        # product, f32-grade results); the last two are inference only.  An attribute, not a constructor argument of
+        # the reference
         self.precision = "fp32"
 
     def _apply(self, fn, *args, **kwargs):
@@ -232,9 +233,12 @@ class DNeRF_Deformation(nn.Module):
             n.pts_b[i] = C.c_void_p(keep[2 * i + 1].data_ptr())
         n.out_w, n.out_b = C.c_void_p(keep[-2].data_ptr()), C.c_void_p(keep[-1].data_ptr())
 
-    def _query_points_bf16(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, L, Lv, Lt):
-        """nrf_dnerf_query_fwd_bf16: one bf16 weight stream for both nets."""
+    def _query_points_bf16(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, L, Lv, Lt, kind="bf16"):
+        """nrf_dnerf_query_fwd_bf16 / _bf16x3: one bf16 (or hi/lo bf16 pair) weight stream for both nets."""
         lib = _lib.lib()
+        f_bytes = getattr(lib, f"nrf_dnerf_{kind}_packed_bytes")
+        f_pack = getattr(lib, f"nrf_dnerf_{kind}_pack_weights")
+        f_query = getattr(lib, f"nrf_dnerf_query_fwd_{kind}")
         occ = self._occ._packed((0, L, Lv))          # its descriptor carries the canonical net's f32 parameter pointers
         occ._fill_pointers()
         tn, e = self._time_desc(L, Lt)
@@ -242,24 +246,23 @@ class DNeRF_Deformation(nn.Module):
         tparams = self._time_params()
         keep = [ops._f32(p.detach(), "time-net parameter") for p in tparams]
         self._fill_time_pointers(tn, keep)
-        vers = (L, Lv, Lt) + tuple((p.data_ptr(), p._version) for p in tparams + list(self._occ.parameters()))
+        vers = (kind, L, Lv, Lt) + tuple((p.data_ptr(), p._version) for p in tparams + list(self._occ.parameters()))
         if self._packed_bf16 is None or vers != self._bf16_versions:
-            nb = lib.nrf_dnerf_bf16_packed_bytes(C.byref(tn), C.byref(occ.net), C.byref(e))
+            nb = f_bytes(C.byref(tn), C.byref(occ.net), C.byref(e))
             if nb <= 0:
-                raise RuntimeError("nrf_dnerf_bf16_packed_bytes: " + lib.nrf_last_error_string().decode())
+                raise RuntimeError(f"nrf_dnerf_{kind}_packed_bytes: " + lib.nrf_last_error_string().decode())
             if self._packed_bf16 is None or self._packed_bf16.numel() != nb:
                 self._packed_bf16 = torch.empty((nb,), device=keep[0].device, dtype=torch.uint8)
-            _lib.check(lib.nrf_dnerf_bf16_pack_weights(C.byref(tn), C.byref(occ.net), C.byref(e),
-                                                       ops._ptr(self._packed_bf16), ops._stream()),
-                       "nrf_dnerf_bf16_pack_weights")
+            _lib.check(f_pack(C.byref(tn), C.byref(occ.net), C.byref(e), ops._ptr(self._packed_bf16), ops._stream()),
+                       f"nrf_dnerf_{kind}_pack_weights")
             self._bf16_versions = vers
         P = pts.shape[0]
         raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
         dx = torch.empty((P, 3), device=pts.device, dtype=torch.float32)
-        _lib.check(lib.nrf_dnerf_query_fwd_bf16(
+        _lib.check(f_query(
             C.byref(tn), C.byref(occ.net), C.byref(e), ops._ptr(self._packed_bf16), ops._ptr(pts), ops._ptr(viewdirs),
             ops._ptr(times), P, int(pts_per_ray), int(bool(times_per_point)), int(netchunk),
-            int(bool(self.zero_canonical)), ops._ptr(raw), ops._ptr(dx), ops._stream()), "nrf_dnerf_query_fwd_bf16")
+            int(bool(self.zero_canonical)), ops._ptr(raw), ops._ptr(dx), ops._stream()), f"nrf_dnerf_query_fwd_{kind}")
         return raw, dx
 
     def query_points(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires, multires_views,
@@ -277,9 +280,11 @@ class DNeRF_Deformation(nn.Module):
             return _DeformFunction.apply(self, pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
                                          int(netchunk), multires, multires_views, multires_time,
                                          *[p for _, p in self.named_parameters()])
-        if self.precision == "bf16":
+        if self.precision in ("bf16", "bf16x3"):
             return self._query_points_bf16(pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires,
-                                           multires_views, multires_time)
+                                           multires_views, multires_time, kind=self.precision)
+        if self.precision != "fp32":
+            raise ValueError(f"nerf_amd: unknown precision {self.precision!r} (fp32, bf16 or bf16x3)")
         self._refresh_time(multires, multires_time)
         occ = self._occ._packed((0, multires, multires_views))
         occ.refresh()

@@ -227,6 +227,45 @@ def test_bf16_deformation_chain(gold_dnerf, parts):
     assert float((raw - raw_ref).abs().max()) < 3e-2 * rs, (float((raw - raw_ref).abs().max()), rs)
 
 
+@pytest.mark.parametrize("peaky,dx_scale", [(False, 1.0), (True, 3.0)])
+def test_bf16x3_deformation_chain(parts, peaky, dx_scale):
+    """nrf_dnerf_query_fwd_bf16x3 (three bf16 MFMAs per product on hi/residual operands) against the exact f32 kernel:
+    dx within 5e-5 of its scale -- the static bf16x3 bar -- on a smooth and on a sharp model.  raw is compared on the
+    same bar for the smooth model; with dx_scale 3 the canonical net sees x + dx through its frequency-512 encoding, which
+    multiplies the f32-rounding-sized differences of dx, so the bar there is 1e-3 of raw's scale."""
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                 input_ch_time=21, output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    sd = fx.make_dnerf_state(35, peaky=peaky, dx_scale=dx_scale)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    rng = np.random.RandomState(5)
+    pts = dev(rng.uniform(-1.5, 1.5, (7, 192, 3)))          # 1344 points: ten full 128-point tiles and a ragged one
+    dirs = dev(fx.blender_rays(7, 2)[:, -3:])
+    times = dev(np.array([[0.0], [0.5], [0.25], [1.0], [0.7], [0.1], [0.9]]))
+    run = lambda nc, t=times: vd.run_network_dnerf(pts, dirs, t, model, embed_fn, embeddirs_fn, embed_time, netchunk=nc)  # noqa: E731
+    with torch.no_grad():
+        raw_ref, dx_ref = run(192)
+        model.precision = "bf16x3"
+        raw, dx = run(192)
+        raw_b, dx_b = run(192)
+        # one chunk whose first time is not 0: the reference's shortcut (network.py:316-320 looks at the chunk's first
+        # time) does not apply, the t == 0 ray goes through the time net like the others
+        raw_w, dx_w = run(1 << 16, times.flip(0))
+        model.precision = "fp32"
+        raw_wref, dx_wref = run(1 << 16, times.flip(0))
+    assert torch.equal(raw, raw_b) and torch.equal(dx, dx_b)
+    assert float(dx[0].abs().max()) == 0.0 and float(dx_ref[0].abs().max()) == 0.0     # t == 0 chunk: no deformation
+    sc = float(dx_ref.abs().max())
+    rs = float(raw_ref.abs().max())
+    e_dx, e_raw = float((dx - dx_ref).abs().max()), float((raw - raw_ref).abs().max())
+    e_dxw, e_raww = float((dx_w - dx_wref).abs().max()), float((raw_w - raw_wref).abs().max())
+    print(f"dx scale {sc:.3e} err {e_dx:.3e} / {e_dxw:.3e}; raw scale {rs:.3e} err {e_raw:.3e} / {e_raww:.3e}")
+    assert max(e_dx, e_dxw) < 5e-5 * max(sc, 1e-3), (e_dx, e_dxw, sc)
+    assert max(e_raw, e_raww) < (1e-3 if peaky else 5e-5) * rs, (e_raw, e_raww, rs)
+
+
 def test_render_path_dnerf(parts):
     vd, model, qfn, _, _ = parts
     kw = dict(network_fn=model, network_query_fn=qfn, N_samples=32, perturb=0., N_importance=32, network_fine=None,

@@ -221,8 +221,9 @@ def test_fern_ndc_full_view_properties():
 
 def test_dnerf_400_view_properties():
     """configs[4] / C5: DNeRF_Deformation default architecture, 400x400, 64+128.  t = 0 with zero_canonical renders the
-    canonical net alone (bit-identical to the static path on `_occ`); t = 0.5: chunk invariance, bf16 within 1e-2 of
-    f32 on a smooth model, away from rays whose last-sample sigma sits at the sign flip (DESIGN: bf16 accuracy)."""
+    canonical net alone (bit-identical to the static path on `_occ`); t = 0.5: chunk invariance, bf16 within 1e-2 and
+    bf16x3 within 1e-4 of f32 on a smooth model, away from rays whose last-sample sigma sits at the sign flip (DESIGN:
+    bf16 accuracy)."""
     import nerf_amd.vanilla_dynamic as vd
     from nerf_amd.network import NeRF
     from nerf_amd.render import render
@@ -257,8 +258,28 @@ def test_dnerf_400_view_properties():
         assert not torch.equal(rgb, rgb0)                                         # the deformation does something
         model.precision = "bf16"
         rgb_b, disp_b, acc_b, _ = vd.render_dnerf(H, W, K, 0.5, chunk=32768, c2w=c2w, near=2., far=6., **kw)
+        model.precision = "bf16x3"
+        rgb_x, disp_x, acc_x, ex_x = vd.render_dnerf(H, W, K, 0.5, chunk=32768, c2w=c2w, near=2., far=6., retraw=True,
+                                                     **kw)
         model.precision = "fp32"
     stable = (ex["raw"][..., -1, 3].abs() > 2e-3).reshape(H, W)
     assert float(stable.float().mean()) > 0.75
     assert float((rgb_b - rgb)[stable].abs().max()) < 1e-2
     assert float((acc_b - acc)[stable].abs().max()) < 1e-2
+    # bf16x3: the coarse pass runs on identical sample positions, so it states the kernel's accuracy at the image level
+    # (1e-5, ten times inside the f32 bar; rays whose last coarse sigma sits within 1e-4 of the sign flip aside).  The
+    # fine pass goes through sample_pdf: this random-init field has near-empty rays (acc ~ 0.07), where a 1e-5
+    # relative change of a coarse weight moves a fine sample by ~1e-3 and the frequency-512 field differs there,
+    # so: 99.5 % of the pixels within the f32 bar of 1e-4, all within 1e-3.
+    e_rgb0, e_acc0 = float((ex_x["rgb0"] - ex["rgb0"]).abs().max()), float((ex_x["acc0"] - ex["acc0"]).abs().max())
+    stable_x = (ex["raw"][..., -1, 3].abs() > 1e-4).reshape(H, W)
+    print(f"D-NeRF bf16x3 vs f32: coarse rgb {e_rgb0:.2e} acc {e_acc0:.2e}; fine rgb "
+          f"{float((rgb_x - rgb)[stable_x].abs().max()):.2e} acc {float((acc_x - acc)[stable_x].abs().max()):.2e}")
+    assert e_rgb0 < 1e-5 and e_acc0 < 1e-5
+    from conftest import assert_mostly_close
+    host = lambda t: t.cpu().numpy()  # noqa: E731
+    assert float(stable_x.float().mean()) > 0.95
+    assert_mostly_close(host(rgb_x)[host(stable_x)], host(rgb)[host(stable_x)], atol=1e-4, frac=0.995, hard=1e-3,
+                        what="D-NeRF bf16x3 rgb")
+    assert_mostly_close(host(acc_x)[host(stable_x)], host(acc)[host(stable_x)], atol=1e-4, frac=0.995, hard=1e-3,
+                        what="D-NeRF bf16x3 acc")
