@@ -342,9 +342,10 @@ def main():
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "traffic": None if x3 else pmc_traffic("render_bf16" if bf16 else "render",
-                                                                "query_fwd_bf16_kernel<8, true>" if bf16
-                                                                else "query_fwd_kernel<8, false, false, false>"),
+                         "traffic": pmc_traffic("render_bf16" if bf16 else ("render_bf16x3" if x3 else "render"),
+                                                "query_fwd_bf16_kernel<8, true>" if bf16
+                                                else ("query_fwd_bf16x3_kernel<8, true>" if x3
+                                                      else "query_fwd_kernel<8, false, false, false>")),
                          "kernel": "query_fwd_bf16_kernel<8,true> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)" if bf16
                          else ("query_fwd_bf16x3_kernel<8,true> (fused PE + MLP, 3 bf16 MFMAs per f32 product; FLOP/s are "
                                "f32-equivalent, peak = bf16 peak / 3)" if x3

@@ -16,13 +16,13 @@ def main(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for w in ("render", "train", "dnerf", "render_bf16"):
+    for w in ("render", "train", "dnerf", "dnerf_bf16", "dnerf_bf16x3", "render_bf16", "render_bf16x3"):
         p = os.path.join(src, f"stats_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{rnd}_{w}_kernel_stats.csv"))
     traffic = {"_note": "per-launch means from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
                         "`bench.py --steps 1` (scripts/profile_gpu.sh); KiB * 1024; fetch_corrected = 2 * fetch_raw"}
-    for w in ("render", "train", "dnerf", "render_bf16"):
+    for w in ("render", "train", "dnerf", "render_bf16", "render_bf16x3"):
         per = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             p = os.path.join(src, f"pmc_{w}_{c}.summary.json")
@@ -45,7 +45,7 @@ def main(tag, rnd):
                 e["hbm_bytes"] = e["fetch_bytes_corrected"] + e["write_bytes"]
         if per:
             # steps executed by the profiled command (scripts/profile_gpu.sh: render 0+1, train 1+1, dnerf 0+1)
-            per["_steps_profiled"] = {"render": 1, "train": 2, "dnerf": 1, "render_bf16": 1}[w]
+            per["_steps_profiled"] = {"render": 1, "train": 2, "dnerf": 1, "render_bf16": 1, "render_bf16x3": 1}[w]
             traffic[w] = per
     out_path = os.path.join(dst, f"{rnd}_pmc_traffic.json")
     if os.path.exists(out_path):

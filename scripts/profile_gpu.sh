@@ -27,11 +27,18 @@ for what in "$@"; do
       done ;;
     sq)   # SQ_COUNTERS="A B C" (<= 8 SQ counters), EXTRA="--precision bf16" etc.
       timeout -s KILL 240 rocprofv3 --pmc $SQ_COUNTERS --output-format csv -d "$OUT/pmc_render_sq" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > "$OUT/pmc_render_sq.log" 2>&1 ;;
-    stats_bf16)
-      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render_bf16" -o render_bf16 -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision bf16 > "$OUT/render_bf16_stats.log" 2>&1 ;;
-    pmc_bf16)
+    stats_bf16|stats_bf16x3)
+      P=${what#stats_}
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render_$P" -o render_$P -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision $P > "$OUT/render_${P}_stats.log" 2>&1 ;;
+    pmc_bf16|pmc_bf16x3)
+      P=${what#pmc_}
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_bf16_$c" -o render_bf16 -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --precision bf16 > "$OUT/pmc_render_bf16_$c.log" 2>&1
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_${P}_$c" -o render_$P -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --precision $P > "$OUT/pmc_render_${P}_$c.log" 2>&1
+      done ;;
+    stats_dnerf)   # the deformation chain at the three precisions, one kernel-trace run each
+      for P in fp32 bf16 bf16x3; do
+        W=dnerf_$P; [ $P = fp32 ] && W=dnerf
+        timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$W" -o $W -- python3 $ROOT/bench.py --workload dnerf --steps 2 --warmup 1 --precision $P > "$OUT/${W}_stats.log" 2>&1
       done ;;
   esac
 done
