@@ -251,6 +251,7 @@ def main():
     import nerf_fixtures as fx
     from nerf_amd import parallel
     from nerf_amd.positional_encoding import get_embedder
+    parallel.warm_up(device)
     from nerf_amd.rays import get_rays
     from nerf_amd.render import render, run_network
 

@@ -26,6 +26,20 @@ def slice_partition(n, world):
     return row_partition(n, world)
 
 
+def warm_up(device, group=None):
+    """One tiny all-reduce and one tiny gather: RCCL connects ring and point-to-point channels on first use, which
+    belongs to start-up, not to the first timed step (bench.py calls this once after init_process_group)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dev = device if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.ones(16, device=dev)
+    dist.all_reduce(t, group=group)
+    gathered = [torch.empty_like(t) for _ in range(dist.get_world_size(group))] if dist.get_rank(group) == 0 else None
+    dist.gather(t, gathered, dst=0, group=group)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+
+
 def render_sharded(render_rows, H, W, rank=None, world=None, group=None):
     """render_rows(row0, nrows) -> [nrows*W, C] tensor on this rank's device (C = 5: rgb, disp, acc).
     Returns the [H, W, C] image on rank 0 (None elsewhere)."""

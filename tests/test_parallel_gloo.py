@@ -25,6 +25,7 @@ def _worker(rank, world, port, H, W, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        parallel.warm_up(torch.device("cpu"))
         # a deterministic stand-in for "render these rows": value = f(row, col)
         def rows(row0, nrows):
             r = torch.arange(row0, row0 + nrows, dtype=torch.float32)[:, None, None]
