@@ -23,6 +23,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's peer setup fails in hipIpcGetMemHandle
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -222,13 +222,22 @@ __device__ __forceinline__ uint32_t relu2(uint32_t p) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
 }
 
-// The weight stream as seen by one wave.  LDS holds THREE 16 KiB stages: chunk c is consumed from stage c%3 while
-// chunk c+1 is already complete in the next stage and chunk c+2 is in flight into the third.  Fragments are read
+// The weight stream as seen by one wave.  LDS holds FOUR 16 KiB stages: chunk c is consumed from stage c%4 while
+// chunk c+1 is already complete in the next stage and chunks c+2, c+3 are in flight into the other two (the mid-chunk
+// wait leaves the youngest chunk's four copies outstanding: loads return in order).  Two chunks in flight cover an L2
+// miss: both nets of the D-NeRF chain as hi/residual pairs are 4.4 MB, more than one XCD's 4 MB L2, and with three
+// stages that kernel stalled on its copies (0.886 -> 0.813 s per 800x800 view; no change where the stream fits in L2).
+// Fragments are read
 // kAhead ahead of the MFMA that uses them, across chunk and layer boundaries, so the matrix pipe never waits for
 // an LDS round trip; the one barrier per chunk sits in the MIDDLE of a chunk, where nothing else is pending.
 constexpr int kAhead = 4;
-constexpr int kStages = 3;
-struct WStream {
+#ifndef NRF_STREAM_STAGES
+#define NRF_STREAM_STAGES 4
+#endif
+constexpr int kStages = NRF_STREAM_STAGES;
+template <int AHEAD>
+struct WStreamT {
+    static constexpr int kDepth = AHEAD;
     __amdgpu_buffer_rsrc_t rsrc;
     char *lds;
     uint32_t total;      // bytes of all chunks (the stream wraps there)
@@ -236,7 +245,7 @@ struct WStream {
     uint32_t st_req;     // stage (byte offset in lds) the next request goes to
     uint32_t rd_cur, rd_nxt;   // this lane's byte offset of fragment 0 in the current / the next chunk's stage
     int lane16, wave;
-    bf16x8 q[kAhead];    // fragments in flight / ready: fragment i of a layer sits in q[i % kAhead]
+    bf16x8 q[AHEAD];     // fragments in flight / ready: fragment i of a layer sits in q[i % AHEAD]
 
     // one of the four 1 KiB pieces this wave copies per chunk; the ring position advances after the last one
     __device__ __forceinline__ void request_piece(int i) {
@@ -259,7 +268,10 @@ struct WStream {
     // the four copies one at a time between MFMAs (each VMEM issue stalls the wave; spread out, the matrix pipe
     // covers part of every stall instead of idling through four in a row).
     __device__ __forceinline__ void publish() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the copies of chunks beyond the next one (4 per chunk and wave, returned in order) may stay in flight
+        if (kStages == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kStages == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -273,25 +285,32 @@ struct WStream {
     }
     __device__ __forceinline__ void start() {
         pf_off = 0; st_req = 0;
-        request();
-        request();
+#pragma unroll
+        for (int i = 0; i < kStages - 1; ++i) request();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         rd_cur = (uint32_t)lane16;
         rd_nxt = (uint32_t)lane16 + kChunk;
 #pragma unroll
-        for (int i = 0; i < kAhead; ++i) q[i] = read(false, i);
+        for (int i = 0; i < AHEAD; ++i) q[i] = read(false, i);
     }
 };
+#ifndef NRF_X3_AHEAD
+#define NRF_X3_AHEAD 4
+#endif
+using WStream = WStreamT<kAhead>;
+using WStreamX3 = WStreamT<NRF_X3_AHEAD>;   // 1.5 MFMAs per fragment instead of 2: the same latency cover needs more fragments in flight
 
 // The N fragments of a layer, in stream order: body(i, a) gets fragment i between two scheduling barriers; around it
 // the chunk protocol runs -- publish the next chunk mid-chunk, copy requests spread over the following fragment slots,
 // LDS reads kAhead fragments ahead across chunk and layer boundaries.  The layer starts on a chunk boundary;
 // N % kAhead == 0 keeps q's phase static.
-template <int N, class Body>
-__device__ __forceinline__ void stream_frags(WStream &st, Body &&body) {
+template <int N, class ST, class Body>
+__device__ __forceinline__ void stream_frags(ST &st, Body &&body) {
+    constexpr int kAhead = ST::kDepth;
     static_assert(N % kAhead == 0 && N >= kAhead, "fragment count of a layer must be a multiple of the read-ahead");
+    static_assert(N % 16 == 0 || N % 16 >= kAhead, "a layer's last chunk must hold at least the read-ahead");
     constexpr int NCH = (N + 15) / 16;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -337,7 +356,7 @@ __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st
 // bf16x3: acc[t] (+)= W * x with W = Wh + Wl, x = xh + xl (bf16 each) as Wh*xh + Wh*xl + Wl*xh.  The stream holds
 // (hi, residual) fragment pairs; one 32-point tile per wave; all three MFMAs of a pair accumulate into the same tile.
 template <int NT_OUT, int S, class BH, class BL>
-__device__ __forceinline__ void gemm_layer_x3(f32x16 (&acc)[NT_OUT], WStream &st, BH &&Bh, BL &&Bl) {
+__device__ __forceinline__ void gemm_layer_x3(f32x16 (&acc)[NT_OUT], WStreamX3 &st, BH &&Bh, BL &&Bl) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     stream_frags<2 * S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
         const int j = i >> 1, s = j / NT_OUT, t = j % NT_OUT;
@@ -590,7 +609,11 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             uint32_t hi, lo;
+#ifdef NRF_X3_NOPACK
+            hi = __float_as_uint(r[2 * w]); lo = __float_as_uint(r[2 * w + 1]);
+#else
             split2(r[2 * w], r[2 * w + 1], hi, lo);
+#endif
             hh[2 * t + (w >> 2)][w & 3] = hi;
             hl[2 * t + (w >> 2)][w & 3] = lo;
         }
@@ -611,7 +634,11 @@ __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
     for (int i = 0; i < NF; ++i) {
         const float sc = pow2i(2 * i + h);
 #pragma unroll
+#ifdef NRF_X3_NOPE
+        for (int d = 0; d < 3; ++d) { v[2 + 6 * i + d] = co[d] * sc; v[2 + 6 * i + 3 + d] = co[d] + sc; }
+#else
         for (int d = 0; d < 3; ++d) sincosf(co[d] * sc, &v[2 + 6 * i + d], &v[2 + 6 * i + 3 + d]);
+#endif
     }
 #pragma unroll
     for (int i = 2 + 6 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
@@ -630,7 +657,7 @@ __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
 template <int NT, int S0, class B0H, class B0L>
 __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
                                             const u32x4v (&xh)[kBfKsX], const u32x4v (&xl)[kBfKsX], const u32x4v &one,
-                                            const u32x4v &none, WStream &st, int n_trunk, int skip_in_mask, B0H &&b0h,
+                                            const u32x4v &none, WStreamX3 &st, int n_trunk, int skip_in_mask, B0H &&b0h,
                                             B0L &&b0l) {
     gemm_layer_x3<NT, S0>(acc, st, b0h, b0l);
     pack_acts_x3<NT>(hh, hl, acc, true);
@@ -652,7 +679,7 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
 template <int NT>
 __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
                                                  const u32x4v (&dh)[kBfKsD], const u32x4v (&dl)[kBfKsD], const u32x4v &one,
-                                                 const u32x4v &none, WStream &st, const float *hb, int64_t pp,
+                                                 const u32x4v &none, WStreamX3 &st, const float *hb, int64_t pp,
                                                  int64_t n_points, int h, float *raw) {
     f32x16 acc1[1];
     gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });      // network.py:56
@@ -677,7 +704,7 @@ template <int NT, bool VIEWS>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
-    WStream st;
+    WStreamX3 st;
     st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
     st.lds = lds;
     st.total = (uint32_t)a.stream_bytes;
@@ -856,7 +883,7 @@ template <int NT>
 __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16x3_kernel(const DnerfBf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
-    WStream st;
+    WStreamX3 st;
     st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
     st.lds = lds;
     st.total = (uint32_t)a.stream_bytes;
