@@ -266,6 +266,35 @@ def test_bf16x3_deformation_chain(parts, peaky, dx_scale):
     assert max(e_raw, e_raww) < (1e-3 if peaky else 5e-5) * rs, (e_raw, e_raww, rs)
 
 
+def test_bf16x3_deformation_chain_small_net(parts):
+    """The W = 128 instantiation (both nets), a point count that is not a multiple of the 128-point pass, no points."""
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    model = vd.DNeRF_Deformation(D=4, W=128, D_deform=4, W_deform=128, input_ch=63, input_ch_views=27,
+                                 input_ch_time=21, output_ch=4, skips=[2], use_viewdirs=True, zero_canonical=True)
+    sd = fx.make_dnerf_state(37, D=4, W=128, D_deform=4, W_deform=128, skips=(2,), dx_scale=1.0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    rng = np.random.RandomState(6)
+    pts = dev(rng.uniform(-1.5, 1.5, (5, 37, 3)))
+    dirs = dev(fx.blender_rays(5, 3)[:, -3:])
+    times = dev(np.array([[0.3], [0.0], [0.8], [1.0], [0.55]]))
+    run = lambda p, d, t: vd.run_network_dnerf(p, d, t, model, embed_fn, embeddirs_fn, embed_time, netchunk=1 << 16)  # noqa: E731
+    with torch.no_grad():
+        raw_ref, dx_ref = run(pts, dirs, times)
+        model.precision = "bf16x3"
+        raw, dx = run(pts, dirs, times)
+        raw0, dx0 = run(pts[:0], dirs[:0], times[:0])
+        # the canonical net in exact f32 at THIS run's deformed points: separates the kernel's own error from what the
+        # frequency-512 encoding makes of the 1e-7-sized differences in dx (this small net has large first-layer weights)
+        raw_at = model._occ.query_points((pts + dx).reshape(-1, 3), dirs, 37, 10, 4).reshape(5, 37, 4)
+    assert raw0.shape == (0, 37, 4) and dx0.shape == (0, 37, 3)
+    sc, rs = float(dx_ref.abs().max()), float(raw_ref.abs().max())
+    assert float((dx - dx_ref).abs().max()) < 5e-5 * max(sc, 1e-3)
+    assert float((raw - raw_at).abs().max()) < 5e-5 * rs, float((raw - raw_at).abs().max()) / rs
+    assert float((raw - raw_ref).abs().max()) < 5e-4 * rs, float((raw - raw_ref).abs().max()) / rs
+
+
 def test_render_path_dnerf(parts):
     vd, model, qfn, _, _ = parts
     kw = dict(network_fn=model, network_query_fn=qfn, N_samples=32, perturb=0., N_importance=32, network_fine=None,
