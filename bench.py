@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--train-rays", type=int, default=4096, help="global ray batch of the train workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-path", action="store_true", help="use the multi-GPU row-sharded code path even with one GPU")
+    ap.add_argument("--graph", action="store_true",
+                    help="render workload, N=1: replay the frame as one captured HIP graph (nerf_amd.render.RenderGraph)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short secondary measurements (N=1 only)")
     ap.add_argument("--cpu-rays", type=int, default=32768, help="rays in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -286,6 +288,8 @@ def main():
     timer = QueryTimer(torch)
     timer.install()
 
+    frame_graph = []
+
     def step(i):
         if fern:   # identity rotation, small lateral motion per step
             c2w = torch.eye(4)[:3, :4].clone()
@@ -294,6 +298,11 @@ def main():
         else:
             c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
         with torch.no_grad():
+            if world == 1 and args.graph:
+                if not frame_graph:
+                    from nerf_amd.render import RenderGraph
+                    frame_graph.append(RenderGraph(H, W, K, chunk=32768, near=near, far=far, **kw))
+                return frame_graph[0](c2w)[0]
             if world == 1 and not args.sharded_path:
                 rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=near, far=far, **kw)
                 return rgb
@@ -326,6 +335,10 @@ def main():
     if rank == 0:
         n_rays = H * W
         q_ms, q_pts, q_n = timer.summary()
+        if args.graph and world == 1:
+            # a replayed graph has no per-launch events: price the query kernel against the WHOLE frame time (a lower
+            # bound of its rate; the default, ungraphed run measures the kernel itself)
+            q_ms, q_pts, q_n = 1e3 * dt, n_rays * (64 + 192) * args.steps, args.steps
         achieved = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12 if q_ms > 0 else 0.0
         out = {
             "metric": "rays/sec at 64+128 samples/ray (render)",

@@ -228,6 +228,39 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
     return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
 
 
+class RenderGraph:
+    """render() of one whole frame captured ONCE as a HIP graph and replayed per pose: the frames of a path share every
+    shape, so the ~250 launches of a frame (20 chunks x sampling, points, two queries, two composites, concatenation)
+    become one graph launch and the GPU no longer waits on the host between the short kernels.  Results are bit-identical
+    to render().  Deterministic renders only (perturb = 0, raw_noise_std = 0: a captured random draw would repeat);
+    static NeRF nets.  The returned tensors are the graph's own buffers: valid until the next call, clone to keep."""
+
+    def __init__(self, H, W, K, chunk=1024 * 32, device="cuda", **render_kwargs):
+        if render_kwargs.get("perturb", 0.) or render_kwargs.get("raw_noise_std", 0.):
+            raise ValueError("nerf_amd.RenderGraph: perturb and raw_noise_std must be 0 (captured noise would repeat)")
+        if render_kwargs.get("rays") is not None:
+            raise ValueError("nerf_amd.RenderGraph renders whole frames from a pose (c2w), not explicit ray batches")
+        K = np.asarray(K.detach().cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float64)   # host scalars only
+        self._nets = [n for n in (render_kwargs.get("network_fn"), render_kwargs.get("network_fine")) if n is not None]
+        self.c2w = torch.eye(4, device=device, dtype=torch.float32)[:3, :4].contiguous()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():       # warm-up off the capture: packs weights, sizes the pools
+            render(H, W, K, chunk=chunk, c2w=self.c2w, **render_kwargs)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.rgb, self.disp, self.acc, self.extras = render(H, W, K, chunk=chunk, c2w=self.c2w, **render_kwargs)
+
+    def __call__(self, c2w):
+        for net in self._nets:                               # parameters may have changed since the capture: the packed
+            for pk in getattr(net, "_packed_cache", {}).values():   # copies the graph reads are refreshed in place
+                pk.refresh()
+        self.c2w.copy_(torch.as_tensor(c2w)[:3, :4], non_blocking=True)
+        self.graph.replay()
+        return self.rgb, self.disp, self.acc, self.extras
+
+
 class _FrameDrain:
     """Streaming of finished frames to the host: frame i's device->host copy, 8-bit quantisation and
     PNG write happen after frame i+1's kernels have been enqueued, so the GPU never idles on host work.  The copy
@@ -267,9 +300,10 @@ class _FrameDrain:
         return np.stack(self.rgbs, 0), np.stack(self.disps, 0)
 
 
-def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0, graph=False):
     """One render() per pose -> (rgbs [N,H,W,3], disps [N,H,W]) as numpy; PNGs into savedir if given.  Same results
-    as the reference's loop (render.py:347-366); host-side work of frame i overlaps the rendering of frame i+1."""
+    as the reference's loop (render.py:347-366); host-side work of frame i overlaps the rendering of frame i+1.
+    graph=True (not in the reference's signature) captures the frame once as a HIP graph and replays it per pose."""
     H, W, focal = hwf
     if render_factor != 0:
         # NB: like the reference (render.py:337-341) K itself is not rescaled here
@@ -277,8 +311,13 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
 
     drain = _FrameDrain(savedir)
     t0 = time.time()
+    frame = RenderGraph(H, W, K, chunk=chunk, **render_kwargs) if graph else None
     for i, c2w in enumerate(render_poses):
-        rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        if frame is not None:
+            rgb, disp, _, _ = frame(c2w)
+            rgb, disp = rgb.clone(), disp.clone()        # the graph's buffers are overwritten by the next frame
+        else:
+            rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
         drain.push(i, rgb, disp)
         if i == 0:
             print(rgb.shape, disp.shape, f"first frame enqueued after {time.time() - t0:.3f}s")
