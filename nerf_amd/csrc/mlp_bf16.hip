@@ -597,15 +597,18 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t 
 
 template <int NT>
 __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&acc)[NT], bool relu) {
-    const float lo_bound = relu ? 0.0f : -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         float r[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r[k]) : "a"(acc[t][k]));
         __builtin_amdgcn_sched_barrier(0);
+        // ReLU as ONE instruction per value: fmaxf() on a value the compiler knows nothing about (it comes out of the asm
+        // above) is preceded by a canonicalising v_max_f32 x, x, x -- twice the work
+        if (relu) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r[k] = fmaxf(r[k], lo_bound);
+            for (int k = 0; k < 16; ++k) asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[k]) : "v"(r[k]));
+        }
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             uint32_t hi, lo;
