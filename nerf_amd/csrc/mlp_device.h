@@ -299,11 +299,18 @@ __device__ __forceinline__ void gemm_hid_side(f32x16 (&acc)[NT_OUT], const f32x1
 
 template <int NT>
 __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], bool relu) {
-    const float lo = relu ? 0.0f : -INFINITY;
+    // One instruction per value beside the accumulator read: fmaxf() on an MFMA result is lowered to a canonicalising
+    // v_max_f32 x, x, x followed by the max itself, and VALU work is not hidden under f32 MFMAs on this chip
+    // (profiles/ubench/mfma_f32_issue.hip).  max(x, 0) on the bit pattern as a signed integer is the same function of
+    // every non-NaN float (negative floats are negative integers, -0.0 included) and is a single v_max_i32.
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[t][r] = fmaxf(src[t][r], lo);
+        for (int r = 0; r < 16; ++r) {
+            const int b = __float_as_int(src[t][r]);
+            dst[t][r] = relu ? __int_as_float(b > 0 ? b : 0) : fmaxf(src[t][r], -INFINITY);   // (a bare copy of the one
+            // ReLU-less move lets the allocator alias the two register sets and the render kernel then spills)
+        }
 }
 
 // lane-local part of  sum_c vec[c] * h[c]  over this lane's channels, then the other half's part.
