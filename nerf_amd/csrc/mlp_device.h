@@ -308,8 +308,13 @@ __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int b = __float_as_int(src[t][r]);
-            dst[t][r] = relu ? __int_as_float(b > 0 ? b : 0) : fmaxf(src[t][r], -INFINITY);   // (a bare copy of the one
-            // ReLU-less move lets the allocator alias the two register sets and the render kernel then spills)
+            if (relu) {
+                dst[t][r] = __int_as_float(b > 0 ? b : 0);
+            } else {   // a move, kept a distinct value: a bare copy lets the allocator alias the two register sets
+                float v = src[t][r];   // and the render kernel then spills 32 registers
+                asm("" : "+v"(v));
+                dst[t][r] = v;
+            }
         }
 }
 
