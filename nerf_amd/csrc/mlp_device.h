@@ -318,6 +318,30 @@ __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)
         }
 }
 
+// relu_move with the NEXT layer's bias loads folded in: as soon as tile t has left the accumulator file its
+// registers are refilled with the next layer's bias, so those loads (an L2 round trip that the first MFMA of a layer
+// otherwise waits for with the matrix pipe idle) are in flight under the remaining tiles' moves.  (Requesting the next
+// layer's first weight group before the move as well was tried: 32 more live registers, and the kernel spills.)
+template <int NT>
+__device__ __forceinline__ void relu_move_bias(f32x16 (&dst)[NT], f32x16 (&acc)[NT], const WBuf &wb, uint32_t b) {
+    asm volatile("" : "+s"(b));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int bits = __float_as_int(acc[t][r]);
+            dst[t][r] = __int_as_float(bits > 0 ? bits : 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = wload(wb, wb.h16, (b + ((t * 4 + g) * 2) * 4) * 4);
+            acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // lane-local part of  sum_c vec[c] * h[c]  over this lane's channels, then the other half's part.
 // Loads are issued a whole tile (4 x 16 B) ahead of their use: left to itself the compiler waits for
 // each load before the next (an L2 round trip per 16 bytes).

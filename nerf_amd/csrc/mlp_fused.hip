@@ -73,7 +73,13 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             if constexpr (TRAIN) store_in_t8<kKsT>(tb, (uint32_t)a.tl.a_tin, tin);
             gemm_in<kKsT, NT>(acc, tin, wb, (uint32_t)pl.l0_w2);
         }
-        relu_move<NT>(hin, acc, true);
+        // every trunk move also fetches the bias of the layer that follows (the next trunk slot, then feature_linear;
+        // with no further NT-tile layer the refill is a harmless re-read of a valid slot)
+        auto bias_after = [&](int l) -> uint32_t {
+            if (l + 1 < pl.n_trunk) return (uint32_t)(pl.trunk_base + (int64_t)l * pl.trunk_stride);
+            return pl.use_viewdirs ? (uint32_t)pl.feat_b : (uint32_t)pl.l0_b;
+        };
+        relu_move_bias<NT>(hin, acc, wb, bias_after(0));
         // TRAIN: a layer's activations (and their ReLU gate bits) are saved by the GEMM that consumes them, four
         // registers per k-group under that group's MFMAs (save_hin); only a layer with no consumer saves in a burst
         auto save_hin = [&](int l) {
@@ -85,17 +91,16 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             };
         };
         for (int l = 1; l < pl.n_trunk; ++l) {
-            const uint32_t slot = (uint32_t)(pl.trunk_base + (int64_t)(l - 1) * pl.trunk_stride);
-            load_bias<NT>(acc, wb, slot);
+            const uint32_t slot = (uint32_t)(pl.trunk_base + (int64_t)(l - 1) * pl.trunk_stride);   // acc holds its bias
             if ((pl.skip_in_mask >> l) & 1) gemm_in<kKsX, NT>(acc, xin, wb, slot + skip_off);
             if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, slot + hid_off, save_hin(l - 1));
             else gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
-            relu_move<NT>(hin, acc, true);
+            relu_move_bias<NT>(hin, acc, wb, bias_after(l));
         }
         if (pl.use_viewdirs) {
             if constexpr (NT >= 2) {
                 const float alpha = head_dot<NT>(hin, wb, (uint32_t)pl.alpha_vec) + wload1(wb, (uint32_t)pl.alpha_b * 4);
-                load_bias<NT>(acc, wb, (uint32_t)pl.feat_b);                                     // network.py:57
+                // network.py:57 -- feature_linear's bias is already in acc (fetched by the last trunk move)
                 if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w, save_hin(pl.n_trunk - 1));
                 else gemm_hid<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w);
                 // the feature vector becomes an MFMA operand: move it out of the accumulator file (no ReLU)
