@@ -462,7 +462,9 @@ extern "C" int nrf_sample_fine(const float *z_vals, const float *weights, int64_
                                int32_t n_importance, const float *u, float *z_samples, float *z_merged,
                                float *z_std, void *stream) {
     if (n_rays != 0) NRF_REQUIRE(z_vals && weights && z_merged, "nrf_sample_fine: null pointer");
-    NRF_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1, "nrf_sample_fine: bad sizes");
+    NRF_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1,
+                "nrf_sample_fine: bad sizes (n_rays=%lld, n_samples=%d: at least 3 coarse samples, i.e. one interior "
+                "weight, are needed; n_importance=%d: at least 1)", (long long)n_rays, n_samples, n_importance);
     if (n_samples - 1 > kMaxBins || n_samples + n_importance > kMaxMerged)
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_sample_fine: N_samples-1 <= %d and N_samples+N_importance <= %d",
                          kMaxBins, kMaxMerged);

@@ -1,0 +1,88 @@
+"""Seeded random architectures / sizes through the fused query (all three precisions) and the full render_rays chain,
+against the oracle: depths, widths, skip positions, encoder sizes, with and without view directions, ragged point
+counts (the fixed cases elsewhere pin the reference's own configurations; these look for what they do not reach)."""
+import numpy as np
+import pytest
+import torch
+
+import nerf_fixtures as fx
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    D = int(rng.randint(2, 9))
+    W = int(rng.choice([64, 128, 256]))
+    L, Lv = int(rng.choice([4, 6, 10])), int(rng.choice([2, 4]))
+    views = bool(rng.randint(0, 2))
+    skip = int(rng.randint(0, D - 1))             # (a skip at the last trunk layer breaks the reference's head fan-in)
+    cfg = dict(D=D, W=W, input_ch=3 + 6 * L, input_ch_views=(3 + 6 * Lv) if views else 0, output_ch=int(rng.choice([4, 5])),
+               skips=(skip,), use_viewdirs=views)
+    n_rays, S = int(rng.randint(1, 40)), int(rng.randint(1, 70))
+    return rng, cfg, L, Lv, n_rays, S
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_net_query_all_precisions(seed):
+    from nerf_amd.network import NeRF
+    rng, cfg, L, Lv, n_rays, S = _case(seed)
+    sd = fx.make_nerf_state(500 + seed, **cfg)
+    net = NeRF(D=cfg["D"], W=cfg["W"], input_ch=cfg["input_ch"], input_ch_views=cfg["input_ch_views"],
+               output_ch=cfg["output_ch"], skips=list(cfg["skips"]), use_viewdirs=cfg["use_viewdirs"])
+    if not cfg["use_viewdirs"]:
+        sd = {k: v for k, v in sd.items() if k in net.state_dict()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.cuda()
+    pts = rng.uniform(-2.5, 2.5, (n_rays, S, 3)).astype(np.float32)
+    d = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    full = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    onet = orc.Net(full, **cfg)
+    want = orc.run_network(pts, d if cfg["use_viewdirs"] else None, onet, L, Lv).reshape(n_rays * S, -1)
+    scale = max(np.abs(want).max(), 1e-6)
+    q = lambda: net.query_points(dev(pts.reshape(-1, 3)), dev(d) if cfg["use_viewdirs"] else None, S, L, Lv)  # noqa: E731
+    with torch.no_grad():
+        got = q().cpu().numpy()
+    assert got.shape == want.shape, (cfg, got.shape, want.shape)
+    assert np.abs(got - want).max() <= 2e-5 * scale, (cfg, n_rays, S, np.abs(got - want).max() / scale)
+    if cfg["W"] in (128, 256):
+        for prec, bar in (("bf16x3", 5e-5), ("bf16", 3e-2)):
+            net.precision = prec
+            with torch.no_grad():
+                g2 = q().cpu().numpy()
+            assert np.abs(g2 - want).max() <= bar * scale, (prec, cfg, n_rays, S, np.abs(g2 - want).max() / scale)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_render_rays_vs_oracle(seed):
+    """Whole chain (coarse sampling, query, composite, inverse-CDF resampling, fine pass) at random sample counts, with
+    well-conditioned nets: positions of the coarse pass bit-exact by construction, rendered values to 1e-4."""
+    from nerf_amd.network import NeRF
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render_rays, run_network
+    rng = np.random.RandomState(2000 + seed)
+    Nc, Nf = int(rng.randint(3, 65)), int(rng.choice([0, 1, 17, 64, 128]))   # resampling needs an interior coarse weight
+    n_rays = int(rng.randint(1, 300))
+    white = bool(rng.randint(0, 2))
+    sds = [fx.make_nerf_state(600 + 2 * seed), fx.make_nerf_state(601 + 2 * seed)]
+    nets = []
+    for sd in sds:
+        net = NeRF(8, 256, 63, 27, 4, [4], True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(net.cuda())
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    rays = fx.blender_rays(n_rays, 50 + seed)
+    with torch.no_grad():
+        ret = render_rays(dev(rays), nets[0], lambda i, v, f: run_network(i, v, f, e10, e4), Nc, N_importance=Nf,
+                          network_fine=nets[1], white_bkgd=white)
+    ref = orc.render_rays(rays, orc.Net(sds[0]), orc.Net(sds[1]), Nc, Nf, False, white)
+    for k in ("rgb_map", "acc_map") + (("rgb0", "acc0") if Nf > 0 else ()):
+        err = np.abs(ret[k].cpu().numpy() - ref[k]).max()
+        assert err < 1e-4, (k, Nc, Nf, n_rays, white, err)
