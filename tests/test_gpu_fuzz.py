@@ -86,3 +86,57 @@ def test_random_render_rays_vs_oracle(seed):
     for k in ("rgb_map", "acc_map") + (("rgb0", "acc0") if Nf > 0 else ()):
         err = np.abs(ret[k].cpu().numpy() - ref[k]).max()
         assert err < 1e-4, (k, Nc, Nf, n_rays, white, err)
+
+
+def _torch_forward64(sd, cfg, x, L, Lv, d=None):
+    """network.py:46-69 with plain torch ops in float64 (the encodings of positional_encoding.py:24-33 included)."""
+    def embed(v, n):
+        out = [v]
+        for k in range(n):
+            out += [torch.sin(v * 2.0 ** k), torch.cos(v * 2.0 ** k)]
+        return torch.cat(out, -1)
+    lin = lambda h, name: torch.nn.functional.linear(h, sd[name + ".weight"], sd[name + ".bias"])  # noqa: E731
+    xp = embed(x, L)
+    h = xp
+    for i in range(cfg["D"]):
+        h = torch.relu(lin(h, f"pts_linears.{i}"))
+        if i in cfg["skips"]:
+            h = torch.cat([xp, h], -1)
+    if cfg["use_viewdirs"]:
+        alpha = lin(h, "alpha_linear")
+        h = torch.cat([lin(h, "feature_linear"), embed(d, Lv)], -1)
+        h = torch.relu(lin(h, "views_linears.0"))
+        return torch.cat([lin(h, "rgb_linear"), alpha], -1)
+    return lin(h, "output_linear")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_net_parameter_gradients(seed):
+    """Training forward + dgrad + wgrad + slab reduction on random architectures and ragged point counts against torch
+    autograd of the same network in float64: every parameter's gradient within 2e-3 of its scale."""
+    from nerf_amd.network import NeRF
+    rng, cfg, L, Lv, n_rays, S = _case(100 + seed)
+    n_rays = n_rays * int(rng.choice([1, 7]))          # up to ~19 000 points: several wgrad chunks
+    sd = fx.make_nerf_state(700 + seed, **cfg)
+    net = NeRF(D=cfg["D"], W=cfg["W"], input_ch=cfg["input_ch"], input_ch_views=cfg["input_ch_views"],
+               output_ch=cfg["output_ch"], skips=list(cfg["skips"]), use_viewdirs=cfg["use_viewdirs"])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if k in net.state_dict()}, strict=False)
+    net = net.cuda()
+    pts = dev(rng.uniform(-2.5, 2.5, (n_rays * S, 3)))
+    d = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    dirs = dev(d / np.linalg.norm(d, axis=-1, keepdims=True))
+    out = net.query_points(pts, dirs if cfg["use_viewdirs"] else None, S, L, Lv)
+    g = dev(rng.normal(size=tuple(out.shape)))
+    (out * g).sum().backward()
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in net.state_dict(keep_vars=True).items()}
+    ref = _torch_forward64(sd64, cfg, pts.double(), L, Lv, dirs.double().repeat_interleave(S, 0))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(),
+                               atol=2e-5 * max(float(ref.detach().abs().max()), 1e-6), rtol=0)
+    (ref * g.double()).sum().backward()
+    used = [k for k in sd64 if cfg["use_viewdirs"] or not k.startswith("views_linears")]
+    for k in used:
+        got, want = dict(net.named_parameters())[k].grad, sd64[k].grad
+        assert got is not None and want is not None, k
+        scale = float(want.abs().max()) + 1e-30
+        err = float((got.double() - want).abs().max()) / scale
+        assert err < 2e-3, (k, cfg, n_rays * S, err)
