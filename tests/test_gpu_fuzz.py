@@ -181,3 +181,45 @@ def test_random_deformation_chain_vs_oracle(seed):
     assert np.abs(raw3.cpu().numpy() - want_raw).max() < 1e-3 * sraw
     zero_rows = (np.abs(want_dx).max(axis=(1, 2)) == 0)
     assert np.array_equal(np.abs(dx.cpu().numpy()).max(axis=(1, 2)) == 0, zero_rows)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sampling_and_compositing_sizes(seed):
+    """Inverse-CDF resampling + merge (bit-exact) and the compositor (forward 3e-6, backward vs the oracle) at random
+    sample counts, with both instantiations of the resampling kernel, empty / spiky / zero weights, given and default
+    u."""
+    from nerf_amd import ops
+    from conftest import bits
+    rng = np.random.RandomState(4000 + seed)
+    S = int(rng.randint(3, 200))
+    Ni = int(rng.randint(1, min(400, 1024 - S)))
+    N = int(rng.randint(1, 200))
+    near, far = (0.0, 1.0) if rng.randint(0, 2) else (2.0, 6.0)
+    rays = fx.blender_rays(N, 70 + seed)
+    rays[:, 6], rays[:, 7] = near, far
+    z = ops.sample_coarse(dev(rays), S).cpu().numpy()
+    w = rng.uniform(0, 1, (N, S)).astype(np.float32) ** float(rng.choice([1, 6, 30]))
+    w[0] = 0.0                                           # all-zero weights: the uniform pdf of the 1e-5 floor
+    if N > 1:
+        w[1] = 0.0
+        w[1, S // 2] = 1.0                               # one spike
+    u = rng.uniform(0, 1, (N, Ni)).astype(np.float32) if rng.randint(0, 2) else None
+    zs, zm, sd = ops.sample_fine(dev(z), dev(w), Ni, dev(u) if u is not None else None)
+    o_zs, o_zm, o_sd = orc.sample_fine(z, w, Ni, u)
+    np.testing.assert_array_equal(bits(zs.cpu().numpy()), bits(o_zs), err_msg=f"z_samples S={S} Ni={Ni} N={N}")
+    np.testing.assert_array_equal(bits(zm.cpu().numpy()), bits(o_zm), err_msg=f"z_merged S={S} Ni={Ni} N={N}")
+    np.testing.assert_allclose(sd.cpu().numpy(), o_sd, atol=1e-6, rtol=1e-5)
+    # compositor on the merged depths
+    St = S + Ni
+    raw = (rng.normal(size=(N, St, 4)) * np.array([1, 1, 1, 4.0])).astype(np.float32)
+    white = bool(rng.randint(0, 2))
+    got = ops.composite_fwd(dev(raw), zm, dev(rays[:, 3:6]), None, white)
+    want = orc.raw2outputs(raw, o_zm, rays[:, 3:6], white)
+    for g, w_, name in zip(got, want, ("rgb", "disp", "acc", "weights", "depth")):
+        if name == "disp":
+            continue                                     # 1 / max(1e-10, depth / acc): unbounded where acc -> 0
+        np.testing.assert_allclose(g.cpu().numpy(), w_, atol=3e-6 * max(1.0, float(np.abs(w_).max())), rtol=0, err_msg=name)
+    g_rgb = rng.normal(size=(N, 3)).astype(np.float32)
+    g_raw = ops.composite_bwd(dev(raw), zm, dev(rays[:, 3:6]), dev(g_rgb), white_bkgd=white)
+    o_graw = orc.raw2outputs_bwd(raw, o_zm, rays[:, 3:6], g_rgb, white)
+    np.testing.assert_allclose(g_raw.cpu().numpy(), o_graw, atol=2e-5 * max(1.0, float(np.abs(o_graw).max())), rtol=0)
