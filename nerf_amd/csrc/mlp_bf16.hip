@@ -355,14 +355,15 @@ __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st
 
 // bf16x3: acc[t] (+)= W * x with W = Wh + Wl, x = xh + xl (bf16 each) as Wh*xh + Wh*xl + Wl*xh.  The stream holds
 // (hi, residual) fragment pairs; one 32-point tile per wave; all three MFMAs of a pair accumulate into the same tile.
-template <int NT_OUT, int S, class BH, class BL>
+// BIAS_LAST: the last k-step is the bias step, whose input is the exact constant 1 (residual 0): Wh * 0 is skipped.
+template <int NT_OUT, int S, bool BIAS_LAST = false, class BH, class BL>
 __device__ __forceinline__ void gemm_layer_x3(f32x16 (&acc)[NT_OUT], WStreamX3 &st, BH &&Bh, BL &&Bl) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     stream_frags<2 * S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
         const int j = i >> 1, s = j / NT_OUT, t = j % NT_OUT;
         if ((i & 1) == 0) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bh(s), s == 0 ? zero : acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bl(s), acc[t], 0, 0, 0);
+            if (!(BIAS_LAST && s == S - 1)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bl(s), acc[t], 0, 0, 0);
         } else {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bh(s), acc[t], 0, 0, 0);
         }
@@ -671,7 +672,7 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
                 [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(hh[s >= kBfKsX ? s - kBfKsX : 0]); },
                 [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(hl[s >= kBfKsX ? s - kBfKsX : 0]); });
         else
-            gemm_layer_x3<NT, 2 * NT + 1>(
+            gemm_layer_x3<NT, 2 * NT + 1, true>(
                 acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                 [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });
         pack_acts_x3<NT>(hh, hl, acc, true);
@@ -687,7 +688,7 @@ __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)
     f32x16 acc1[1];
     gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });      // network.py:56
     const float alpha = acc1[0][0] + hb[kHbAlpha];
-    gemm_layer_x3<NT, 2 * NT + 1>(acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
+    gemm_layer_x3<NT, 2 * NT + 1, true>(acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                                   [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });   // network.py:57
     pack_acts_x3<NT>(hh, hl, acc, false);
     f32x16 acc2[NT / 2];
