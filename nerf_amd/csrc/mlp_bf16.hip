@@ -613,11 +613,7 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             uint32_t hi, lo;
-#ifdef NRF_X3_NOPACK
-            hi = __float_as_uint(r[2 * w]); lo = __float_as_uint(r[2 * w + 1]);
-#else
             split2(r[2 * w], r[2 * w + 1], hi, lo);
-#endif
             hh[2 * t + (w >> 2)][w & 3] = hi;
             hl[2 * t + (w >> 2)][w & 3] = lo;
         }
@@ -625,7 +621,7 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
     }
 }
 
-// gamma(v) of a 3-vector (slot order of bf_pe3_chan), every frequency by an accurate sincosf: the recurrence of
+// gamma(v) of a 3-vector (slot order of bf_pe3_chan), every frequency by an accurate sincos (nrf_sincos): the recurrence of
 // fill_pe3_bf16 is only good to ~2^-16
 template <int KS>
 __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], float x, float y, float z, int h) {
@@ -634,16 +630,14 @@ __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
     v[0] = h ? z : x;
     v[1] = h ? 1.0f : y;
     const float co[3] = {x, y, z};
+    sincos_dispatch(fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) * pow2i(2 * NF - 1), [&](auto sc_fn) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const float sc = pow2i(2 * i + h);
+        for (int i = 0; i < NF; ++i) {
+            const float sc = pow2i(2 * i + h);
 #pragma unroll
-#ifdef NRF_X3_NOPE
-        for (int d = 0; d < 3; ++d) { v[2 + 6 * i + d] = co[d] * sc; v[2 + 6 * i + 3 + d] = co[d] + sc; }
-#else
-        for (int d = 0; d < 3; ++d) sincosf(co[d] * sc, &v[2 + 6 * i + d], &v[2 + 6 * i + 3 + d]);
-#endif
-    }
+            for (int d = 0; d < 3; ++d) sc_fn(co[d] * sc, &v[2 + 6 * i + d], &v[2 + 6 * i + 3 + d]);
+        }
+    });
 #pragma unroll
     for (int i = 2 + 6 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
 #pragma unroll
@@ -867,8 +861,10 @@ __device__ __forceinline__ void fill_pe1_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
     constexpr int NF = (8 * KS - 1) / 2;
     float v[8 * KS];
     v[0] = h ? 0.0f : t;
+    sincos_dispatch(fabsf(t) * pow2i(2 * NF - 1), [&](auto sc_fn) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i) sincosf(t * pow2i(2 * i + h), &v[1 + 2 * i], &v[2 + 2 * i]);
+        for (int i = 0; i < NF; ++i) sc_fn(t * pow2i(2 * i + h), &v[1 + 2 * i], &v[2 + 2 * i]);
+    });
 #pragma unroll
     for (int i = 1 + 2 * NF; i < 8 * KS; ++i) v[i] = 0.0f;
 #pragma unroll

@@ -499,22 +499,54 @@ __device__ __forceinline__ void store_in_t8(const TBuf &tb, uint32_t sec, const 
 
 __device__ __forceinline__ float pow2i(int f) { return __int_as_float((127 + f) << 23); }
 
+// sin and cos of one encoder argument, |a| <= kSincosMax (every frequency of a scene-sized coordinate: x * 2^9 with
+// |x| <= 32; callers test their largest argument and use the library's sincosf beyond it).  Two-FMA Cody-Waite
+// reduction by pi/2 (n * c is exact inside the FMA), degree-7/8 minimax polynomials on [-pi/4, pi/4]: max abs error
+// 9.3e-8 over x * 2^k, x in [-6, 6], k = 0..9 (libm's float sin: 7e-8) -- about half the instructions of ocml's
+// sincosf, whose large-argument path rides along in every inlined copy.
+constexpr float kSincosMax = 16384.0f;
+__device__ __forceinline__ void nrf_sincos(float a, float *sn, float *cs) {
+    const float n = rintf(a * 0.636619747f);
+    float r = fmaf(-n, 1.57079637f, a);
+    r = fmaf(-n, -4.37113883e-8f, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(r2, ps, -1.6666654611e-1f);
+    const float s = fmaf(r * r2, ps, r);
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(r2, pc, 4.166664568298827e-2f);
+    const float c = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const int q = (int)n;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = __int_as_float(__float_as_int(ss) ^ ((q & 2) << 30));
+    *cs = __int_as_float(__float_as_int(cc) ^ (((q + 1) & 2) << 30));
+}
+// body(fn) with fn = the fast routine when every lane's largest argument is within range, else the library's
+template <class Body>
+__device__ __forceinline__ void sincos_dispatch(float amax, Body &&body) {
+    if (__builtin_expect(__all(amax <= kSincosMax), 1)) body([](float a, float *s, float *c) { nrf_sincos(a, s, c); });
+    else body([](float a, float *s, float *c) { sincosf(a, s, c); });
+}
+
 // gamma(v) for a 3-vector into the static k-step slots of BLK_PE3 (see blk_chan)
 template <int KS>
 __device__ __forceinline__ void fill_pe3(float (&xin)[KS], float x, float y, float z, int L, int h) {
     constexpr int NPAIR = (KS - 2) / 6;
+    const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) * pow2i(L > 0 ? L - 1 : 0);
+    sincos_dispatch(amax, [&](auto sc_fn) {
 #pragma unroll
-    for (int j = 0; j < NPAIR; ++j) {
-        const int f = 2 * j + h;
-        const bool valid = f < L;
-        const float sc = valid ? pow2i(f) : 0.0f;
-        float sx, cx, sy, cy, sz, cz;
-        sincosf(x * sc, &sx, &cx);   // x * 2^f is exact, as in positional_encoding.py:29
-        sincosf(y * sc, &sy, &cy);
-        sincosf(z * sc, &sz, &cz);
-        xin[6 * j + 0] = sx; xin[6 * j + 1] = sy; xin[6 * j + 2] = sz;
-        xin[6 * j + 3] = valid ? cx : 0.0f; xin[6 * j + 4] = valid ? cy : 0.0f; xin[6 * j + 5] = valid ? cz : 0.0f;
-    }
+        for (int j = 0; j < NPAIR; ++j) {
+            const int f = 2 * j + h;
+            const bool valid = f < L;
+            const float sc = valid ? pow2i(f) : 0.0f;
+            float sx, cx, sy, cy, sz, cz;
+            sc_fn(x * sc, &sx, &cx);   // x * 2^f is exact, as in positional_encoding.py:29
+            sc_fn(y * sc, &sy, &cy);
+            sc_fn(z * sc, &sz, &cz);
+            xin[6 * j + 0] = sx; xin[6 * j + 1] = sy; xin[6 * j + 2] = sz;
+            xin[6 * j + 3] = valid ? cx : 0.0f; xin[6 * j + 4] = valid ? cy : 0.0f; xin[6 * j + 5] = valid ? cz : 0.0f;
+        }
+    });
 #pragma unroll
     for (int s = 6 * NPAIR; s < KS - 2; ++s) xin[s] = 0.0f;
     xin[KS - 2] = h == 0 ? x : y;
@@ -525,15 +557,17 @@ __device__ __forceinline__ void fill_pe3(float (&xin)[KS], float x, float y, flo
 template <int KS>
 __device__ __forceinline__ void fill_pe1(float (&tin)[KS], float t, int L, int h) {
     constexpr int NPAIR = (KS - 1) / 2;
+    sincos_dispatch(fabsf(t) * pow2i(L > 0 ? L - 1 : 0), [&](auto sc_fn) {
 #pragma unroll
-    for (int j = 0; j < NPAIR; ++j) {
-        const int f = 2 * j + h;
-        const bool valid = f < L;
-        float s, c;
-        sincosf(t * (valid ? pow2i(f) : 0.0f), &s, &c);
-        tin[2 * j] = s;
-        tin[2 * j + 1] = valid ? c : 0.0f;
-    }
+        for (int j = 0; j < NPAIR; ++j) {
+            const int f = 2 * j + h;
+            const bool valid = f < L;
+            float s, c;
+            sc_fn(t * (valid ? pow2i(f) : 0.0f), &s, &c);
+            tin[2 * j] = s;
+            tin[2 * j + 1] = valid ? c : 0.0f;
+        }
+    });
 #pragma unroll
     for (int s = 2 * NPAIR; s < KS - 1; ++s) tin[s] = 0.0f;
     tin[KS - 1] = h == 0 ? t : 0.0f;

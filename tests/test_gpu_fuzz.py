@@ -223,3 +223,31 @@ def test_random_sampling_and_compositing_sizes(seed):
     g_raw = ops.composite_bwd(dev(raw), zm, dev(rays[:, 3:6]), dev(g_rgb), white_bkgd=white)
     o_graw = orc.raw2outputs_bwd(raw, o_zm, rays[:, 3:6], g_rgb, white)
     np.testing.assert_allclose(g_raw.cpu().numpy(), o_graw, atol=2e-5 * max(1.0, float(np.abs(o_graw).max())), rtol=0)
+
+
+def test_encoder_arguments_beyond_the_fast_range():
+    """The in-kernel sincos is a short-range routine up to |x * 2^k| = 16384 and the library's beyond (decided per wave):
+    coordinates of +-100 at L = 10 (arguments up to 51 200) -- alone, and mixed with ordinary points -- against the
+    oracle, f32 and bf16x3; the deformation chain with a far point as well."""
+    from nerf_amd.network import NeRF
+    sd = fx.make_nerf_state(24)
+    net = NeRF(8, 256, 63, 27, 4, [4], True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda()
+    rng = np.random.RandomState(9)
+    far = rng.uniform(-100, 100, (6, 40, 3)).astype(np.float32)
+    mixed = far.copy()
+    mixed[::2] = rng.uniform(-2, 2, mixed[::2].shape)
+    mixed[1, 3] = [16384.0 / 512, -16384.0 / 512, 32.000004]      # at and just past the switch-over
+    d = fx.blender_rays(6, 5)[:, -3:]
+    onet = orc.Net(sd)
+    for pts in (far, mixed):
+        want = orc.run_network(pts, d, onet).reshape(-1, 4)
+        scale = np.abs(want).max()
+        with torch.no_grad():
+            net.precision = "fp32"
+            got = net.query_points(dev(pts.reshape(-1, 3)), dev(d), 40, 10, 4).cpu().numpy()
+            net.precision = "bf16x3"
+            got3 = net.query_points(dev(pts.reshape(-1, 3)), dev(d), 40, 10, 4).cpu().numpy()
+        assert np.abs(got - want).max() < 2e-5 * scale, np.abs(got - want).max() / scale
+        assert np.abs(got3 - want).max() < 5e-5 * scale, np.abs(got3 - want).max() / scale
