@@ -403,9 +403,11 @@ __device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float 
     v[1] = h ? 1.0f : y;
     const float sc = pow2i(h);
     float s[3], c[3];
-    sincosf(x * sc, &s[0], &c[0]);
-    sincosf(y * sc, &s[1], &c[1]);
-    sincosf(z * sc, &s[2], &c[2]);
+    sincos_dispatch(fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) * 2.0f, [&](auto sc_fn) {
+        sc_fn(x * sc, &s[0], &c[0]);
+        sc_fn(y * sc, &s[1], &c[1]);
+        sc_fn(z * sc, &s[2], &c[2]);
+    });
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
 #pragma unroll
@@ -755,7 +757,7 @@ __device__ __forceinline__ void fill_pe1_bf16(u32x4v (&out)[KS], float t, int h)
     float v[8 * KS];
     v[0] = h ? 0.0f : t;
     float s, c;
-    sincosf(t * pow2i(h), &s, &c);
+    sincos_dispatch(fabsf(t) * 2.0f, [&](auto sc_fn) { sc_fn(t * pow2i(h), &s, &c); });
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         v[1 + 2 * i] = s;
