@@ -373,7 +373,7 @@ def main():
         out["hbm_kernels"] = hbm_kernels(torch, device)
         if world == 1 and not args.no_extras and args.workload == "render" and not bf16 and not x3:
             out["also"] = extras(args, torch, dist, device, coarse, fine, step, timer)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays)
         print(json.dumps(out), flush=True)
     if world > 1:
