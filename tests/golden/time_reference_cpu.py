@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Build-container only (the reference never travels to the GPU box): time the IMPORTED reference's PyTorch CPU path
+"""Test infrastructure (it runs the oracle and the imported reference; never part of the product path).  Build-container only (the reference never travels to the GPU box): time the IMPORTED reference's PyTorch CPU path
 and the C oracle port (oracle/liborc.so) on the same rays, same weights, same thread count, so that the `cpu_baseline`
 of bench.py -- the port, timed on the GPU box's host cores -- can be read as a statement about the reference.
   C1 (BASELINE configs[0]): render() of one 100x100 view, 64 coarse + 128 fine samples, D=8 W=256 coarse+fine, no_grad
   C3: one 4096-ray training step, forward + backward through both nets (no optimizer step), reference only
 Import recipe as tests/golden/make_golden.py (imageio -- PNG writing only -- replaced by an empty module object).
-    python scripts/time_reference_cpu.py > profiles/r1_cpu_reference_timing.json"""
+    python tests/golden/time_reference_cpu.py > profiles/r1_cpu_reference_timing.json"""
 import json
 import os
 import statistics
@@ -15,7 +15,7 @@ import types
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
