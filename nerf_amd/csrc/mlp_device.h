@@ -116,7 +116,9 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     const int W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
     if (W < 32 || W > 256 || W % 32) return "W must be a multiple of 32 in [32, 256]";
     if (D < 1 || D > NRF_MAX_D) return "D must be in [1, 16]";
-    if (net->skips_mask >> (D - 1)) return "a skip at the last trunk layer is not supported (nor by the reference)";
+    // a skip index >= D never fires in the reference's loop (network.py:49-53) and is ignored here too; index D - 1
+    // would widen the trunk's output, which the reference's heads cannot take either
+    if ((net->skips_mask >> (D - 1)) & 1) return "a skip at the last trunk layer is not supported (nor by the reference)";
     const bool views = net->use_viewdirs != 0 && time_ch == 0;
     if (views && (W / 2) % 32) return "use_viewdirs needs W/2 to be a multiple of 32";
     pl.nt = W / 32;

@@ -1,9 +1,8 @@
 """Counterpart of vanilla_dynamic/model.py: create_dnerf :25-186, save_checkpoint :189-211, load_checkpoint :214-240.
 Same argument names, same render_kwargs dictionaries, same checkpoint keys."""
-import os
-
 import torch
 
+from .. import _setup
 from ..optim import make_adam
 from .network import DNeRF_Deformation, DNeRF_Straightforward
 from .positional_encoding import get_embedder, get_time_embedder
@@ -17,39 +16,32 @@ def _safe_load(path):
 
 
 def create_dnerf(args):
-    include_input = not getattr(args, 'no_include_input', False)
-    embed_fn, input_ch = get_embedder(args.multires, args.i_embed, input_dims=3, include_input=include_input)
-    input_ch_views, embeddirs_fn = 0, None
-    if args.use_viewdirs:
-        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed, input_dims=3,
-                                                    include_input=include_input)
-    embed_time_fn, input_ch_time = get_time_embedder(args.multires_time, include_input=include_input)
+    """-> (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer), vanilla_dynamic/model.py:25-186."""
+    with_input = not getattr(args, 'no_include_input', False)
+    embed_fn, pos_ch = get_embedder(args.multires, args.i_embed, input_dims=3, include_input=with_input)
+    embeddirs_fn, dir_ch = (get_embedder(args.multires_views, args.i_embed, input_dims=3, include_input=with_input)
+                            if args.use_viewdirs else (None, 0))
+    embed_time_fn, time_ch = get_time_embedder(args.multires_time, include_input=with_input)
+    two_pass = args.N_importance > 0
+    straight = args.network_type == 'straightforward'
+    common = dict(input_ch=pos_ch, input_ch_views=dir_ch, input_ch_time=time_ch, output_ch=5 if two_pass else 4,
+                  skips=[4], use_viewdirs=args.use_viewdirs)
 
-    output_ch = 5 if args.N_importance > 0 else 4
-    skips = [4]
-
-    def make(D, W):
-        if args.network_type == 'straightforward':
-            return DNeRF_Straightforward(D=D, W=W, input_ch=input_ch, output_ch=output_ch, skips=skips,
-                                         input_ch_views=input_ch_views, input_ch_time=input_ch_time,
-                                         use_viewdirs=args.use_viewdirs).to(device)
-        m = DNeRF_Deformation(D=D, W=W, D_deform=8, W_deform=256, input_ch=input_ch, output_ch=output_ch,
-                              skips=skips, skips_deform=skips, input_ch_views=input_ch_views,
-                              input_ch_time=input_ch_time, use_viewdirs=args.use_viewdirs,
-                              zero_canonical=args.zero_canonical,
-                              use_layernorm=getattr(args, 'use_layernorm', False)).to(device)
+    def net(depth, width):
+        if straight:
+            return DNeRF_Straightforward(D=depth, W=width, **common).to(device)
+        # the deformation net's size is fixed at 8 x 256 and its skips follow the canonical net's (model.py:75-77)
+        m = DNeRF_Deformation(D=depth, W=width, D_deform=8, W_deform=256, skips_deform=common['skips'],
+                              zero_canonical=args.zero_canonical, use_layernorm=getattr(args, 'use_layernorm', False),
+                              **common).to(device)
         m.embed_fn = embed_fn
         return m
 
-    model = make(args.netdepth, args.netwidth)
-    model_fine = None
-    if args.N_importance > 0 and (args.network_type == 'straightforward'
-                                  or getattr(args, 'use_two_models_for_fine', False)):
-        model_fine = make(args.netdepth_fine, args.netwidth_fine)
-
-    grad_vars = list(model.parameters())
-    if model_fine is not None:
-        grad_vars += list(model_fine.parameters())
+    coarse = net(args.netdepth, args.netwidth)
+    # one deformation model serves both passes unless asked otherwise (model.py:93-104)
+    own_fine = two_pass and (straight or getattr(args, 'use_two_models_for_fine', False))
+    fine = net(args.netdepth_fine, args.netwidth_fine) if own_fine else None
+    grad_vars = [p for m in (coarse, fine) if m is not None for p in m.parameters()]
 
     def network_query_fn(inputs, viewdirs, times, network_fn):
         return run_network_dnerf(inputs, viewdirs, times, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
@@ -57,56 +49,10 @@ def create_dnerf(args):
                                  network_type=args.network_type)
 
     optimizer = make_adam(grad_vars, lr=args.lrate, betas=(0.9, 0.999))   # vanilla_dynamic/model.py:115
-
-    start = 0
-    if args.ft_path is not None and args.ft_path != 'None':
-        ckpts = [args.ft_path]
-    else:
-        ckpt_dir = os.path.join(args.basedir, args.expname)
-        best_ckpt = os.path.join(ckpt_dir, 'best.tar')
-        if os.path.exists(best_ckpt):
-            ckpts = [best_ckpt]
-            print(f'Using best checkpoint: {best_ckpt}')
-        elif os.path.exists(ckpt_dir):
-            ckpts = [os.path.join(ckpt_dir, f) for f in sorted(os.listdir(ckpt_dir)) if 'tar' in f]
-        else:
-            ckpts = []
-            print(f'Warning: Checkpoint directory {ckpt_dir} does not exist.')
-
-    print('Found ckpts', ckpts)
-    if len(ckpts) > 0 and not args.no_reload:
-        ckpt_path = ckpts[-1]
-        print('Reloading from', ckpt_path)
-        ckpt = _safe_load(ckpt_path)
-        start = ckpt.get('global_step', 0)
-        model.load_state_dict(ckpt.get('network_fn_state_dict', {}), strict=True)
-        if model_fine is not None and 'network_fine_state_dict' in ckpt:
-            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
-        try:
-            if 'optimizer_state_dict' in ckpt:
-                optimizer.load_state_dict(ckpt['optimizer_state_dict'])
-        except ValueError as e:
-            print(f'Warning: Could not load optimizer state (OK for rendering): {e}')
-        print(f'[OK] Checkpoint loaded successfully! (step {start})')
-
-    render_kwargs_train = {
-        'network_query_fn': network_query_fn,
-        'perturb': args.perturb,
-        'N_importance': args.N_importance,
-        'network_fine': model_fine,
-        'N_samples': args.N_samples,
-        'network_fn': model,
-        'use_viewdirs': args.use_viewdirs,
-        'white_bkgd': args.white_bkgd,
-        'raw_noise_std': args.raw_noise_std,
-        'network_type': args.network_type,
-        'ndc': False,
-        'lindisp': args.lindisp,
-    }
-    render_kwargs_test = dict(render_kwargs_train)
-    render_kwargs_test['perturb'] = False
-    render_kwargs_test['raw_noise_std'] = 0.
-    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+    start = _setup.resume(args, coarse, fine, optimizer, device, prefer_best=True, lenient=True)
+    train, test = _setup.render_kwargs(args, network_query_fn, coarse, fine, network_type=args.network_type,
+                                       ndc=False, lindisp=args.lindisp)
+    return train, test, start, grad_vars, optimizer
 
 
 def save_checkpoint(path, global_step, network_fn, network_fine, optimizer, args):

@@ -265,6 +265,19 @@ class DNeRF_Deformation(nn.Module):
             int(bool(self.zero_canonical)), ops._ptr(raw), ops._ptr(dx), ops._stream()), f"nrf_dnerf_query_fwd_{kind}")
         return raw, dx
 
+    def _query_points_two_launch(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, L, Lv, Lt):
+        """The chain as time-net launch -> x + dx -> canonical launch (the kernels of the training path, nothing kept):
+        same arithmetic as the fused kernel, for nets of different widths."""
+        tnet = self._time_packed(L, Lt)
+        dx, _ = tnet.query_train(pts, times, pts_per_ray, times_per_point)
+        if self.zero_canonical:   # network.py:315-322: a netchunk whose FIRST point has t == 0 skips the time net
+            P = pts.shape[0]
+            t_pt = times if times_per_point else times.repeat_interleave(pts_per_ray)
+            first = (torch.arange(P, device=pts.device) // netchunk) * netchunk
+            dx = torch.where((t_pt[first] == 0.0)[:, None], torch.zeros_like(dx), dx)
+        raw = self._occ._packed((0, L, Lv)).query(pts + dx, viewdirs, pts_per_ray)
+        return raw, dx
+
     def query_points(self, pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires, multires_views,
                      multires_time):
         """Fused deformation chain on raw inputs: pts [P,3], viewdirs [P/pts_per_ray,3], times [P] or
@@ -280,6 +293,14 @@ class DNeRF_Deformation(nn.Module):
             return _DeformFunction.apply(self, pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
                                          int(netchunk), multires, multires_views, multires_time,
                                          *[p for _, p in self.named_parameters()])
+        if self.W != self.W_deform:
+            # create_dnerf fixes the deformation net at 8 x 256 whatever --netwidth says (vanilla_dynamic/model.py:75-77);
+            # the fused chain kernels need both nets at one width, so unequal widths run the chain as its two halves
+            if self.precision != "fp32":
+                raise ValueError(f"nerf_amd: precision {self.precision!r} needs the deformation and canonical nets at "
+                                 f"the same width (W_deform = {self.W_deform}, W = {self.W})")
+            return self._query_points_two_launch(pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
+                                                 int(netchunk), multires, multires_views, multires_time)
         if self.precision in ("bf16", "bf16x3"):
             return self._query_points_bf16(pts, viewdirs, times, pts_per_ray, times_per_point, netchunk, multires,
                                            multires_views, multires_time, kind=self.precision)

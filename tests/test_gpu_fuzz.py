@@ -251,3 +251,37 @@ def test_encoder_arguments_beyond_the_fast_range():
             got3 = net.query_points(dev(pts.reshape(-1, 3)), dev(d), 40, 10, 4).cpu().numpy()
         assert np.abs(got - want).max() < 2e-5 * scale, np.abs(got - want).max() / scale
         assert np.abs(got3 - want).max() < 5e-5 * scale, np.abs(got3 - want).max() / scale
+
+
+@pytest.mark.parametrize("W,D", [(64, 2), (128, 4)])
+def test_deformation_chain_with_unequal_widths(W, D):
+    """create_dnerf builds the deformation net at 8 x 256 whatever --netwidth is: the chain then runs as two launches
+    (time net, canonical net) instead of the fused kernel -- same results against the oracle, t = 0 shortcut included;
+    the bf16 modes, which only exist fused, say so."""
+    import nerf_amd.vanilla_dynamic as vd
+    rng = np.random.RandomState(77 + W)
+    sd = fx.make_dnerf_state(900 + W, D=D, W=W, D_deform=8, W_deform=256, skips=(4,), dx_scale=1.0)
+    model = vd.DNeRF_Deformation(D=D, W=W, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27, input_ch_time=21,
+                                 output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    embed_fn, _ = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = vd.get_time_embedder(10)
+    model.embed_fn = embed_fn
+    n_rays, S = 5, 33
+    pts = rng.uniform(-1.5, 1.5, (n_rays, S, 3)).astype(np.float32)
+    dirs = fx.blender_rays(n_rays, 8)[:, -3:]
+    times = np.array([[0.6], [0.0], [0.2], [0.9], [0.35]], np.float32)
+    run = lambda nc: vd.run_network_dnerf(dev(pts), dev(dirs), dev(times), model, embed_fn, embeddirs_fn, embed_time,  # noqa: E731
+                                          netchunk=nc)
+    for nc in (S, 1 << 16):
+        want_raw, want_dx = orc.run_network_dnerf(pts, dirs, times, orc.Net(sd, D=D, W=W, skips=(4,), prefix="_occ."),
+                                                  orc.TimeNet(sd), netchunk=nc)
+        with torch.no_grad():
+            raw, dx = run(nc)
+        assert np.abs(dx.cpu().numpy() - want_dx).max() < 2e-5 * max(np.abs(want_dx).max(), 1e-3)
+        assert np.abs(raw.cpu().numpy() - want_raw).max() < 2e-4 * np.abs(want_raw).max()
+    model.precision = "bf16"
+    with torch.no_grad(), pytest.raises(ValueError, match="same width"):
+        run(S)
