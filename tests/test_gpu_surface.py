@@ -84,3 +84,32 @@ def test_straightforward_network_and_dnerf_checkpoint_helpers(tmp_path):
     assert step == 1234 and saved_args['network_type'] == 'straightforward'
     for (k, p), (_, q) in zip(coarse.state_dict().items(), other['network_fn'].state_dict().items()):
         assert torch.equal(p, q), k
+
+
+def test_documented_ctypes_binding():
+    """INTEGRATION.md section 3, as written there: a plain ctypes call of one entry point with raw device pointers,
+    against the package's own wrapper; and the error path (status code + nrf_last_error_string)."""
+    import ctypes as C
+    import os
+    from nerf_amd import ops
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf_amd", "libnrf.so"))
+    lib.nrf_composite_fwd.restype = C.c_int
+    lib.nrf_last_error_string.restype = C.c_char_p
+    rng = np.random.RandomState(2)
+    N, S = 37, 50
+    raw, rays_d = dev(rng.normal(size=(N, S, 4))), dev(rng.normal(size=(N, 3)))
+    z_vals = dev(np.sort(rng.uniform(2, 6, (N, S)), -1))
+    rgb = torch.empty(N, 3, device="cuda")
+    disp, acc, depth = (torch.empty(N, device="cuda") for _ in range(3))
+    weights = torch.empty(N, S, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = lib.nrf_composite_fwd(p(raw), p(z_vals), p(rays_d), 3, C.c_int64(N), S, None, 1,
+                               p(rgb), p(disp), p(acc), p(weights), p(depth), st)
+    assert rc == 0, lib.nrf_last_error_string().decode()
+    want = ops.composite_fwd(raw, z_vals, rays_d, None, True)
+    for got, w in zip((rgb, disp, acc, weights, depth), want):
+        assert torch.equal(got, w)
+    rc = lib.nrf_composite_fwd(p(raw), p(z_vals), p(rays_d), 3, C.c_int64(N), 0, None, 1,
+                               p(rgb), p(disp), p(acc), p(weights), p(depth), st)
+    assert rc != 0 and b"nrf_composite_fwd" in lib.nrf_last_error_string()
