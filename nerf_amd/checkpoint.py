@@ -101,7 +101,7 @@ def networks_from_checkpoint(path, device="cuda", precision="fp32"):
 
 
 def packed_from_checkpoint(path, which="network_fn", device="cuda", precision="fp32"):
-    """A static-NeRF checkpoint straight to the packed kernel layout -> ops.PackedNet / ops.PackedNetBf16 (query-ready,
+    """A static-NeRF checkpoint straight to the packed kernel layout -> ops.PackedNet / PackedNetBf16 / PackedNetBf16x3 (query-ready,
     raw points in, positional encoding fused).  which: 'network_fn' | 'network_fine'."""
     from . import ops
     sd = read_checkpoint(path)[f"{which}_state_dict"]
@@ -110,7 +110,10 @@ def packed_from_checkpoint(path, which="network_fn", device="cuda", precision="f
     a = infer_nerf_arch(sd)
     params = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in sd.items()}
     L, Lv = _multires(a["input_ch"]), _multires(a["input_ch_views"]) if a["use_viewdirs"] else 0
-    cls = {"fp32": ops.PackedNet, "bf16": ops.PackedNetBf16}[precision]
+    known = {"fp32": ops.PackedNet, "bf16": ops.PackedNetBf16, "bf16x3": ops.PackedNetBf16x3}
+    if precision not in known:
+        raise ValueError(f"precision must be one of {sorted(known)}, not {precision!r}")
+    cls = known[precision]
     kw = dict(multires=L, multires_views=Lv)
     if precision == "fp32":
         kw["mode"] = 0

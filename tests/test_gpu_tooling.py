@@ -161,6 +161,10 @@ def test_checkpoint_to_modules_and_packed(tab):
     pkb = ck.packed_from_checkpoint(CKPT, "network_fine", precision="bf16")
     rawb = pkb.query(pts, dirs, 1)
     assert float((rawb - raw).abs().max()) < 3e-2 * max(1.0, float(raw.abs().max()))
+    raw3 = ck.packed_from_checkpoint(CKPT, "network_fine", precision="bf16x3").query(pts, dirs, 1)
+    assert float((raw3 - raw).abs().max()) < 5e-5 * max(1.0, float(raw.abs().max()))
+    with pytest.raises(ValueError, match="precision"):
+        ck.packed_from_checkpoint(CKPT, "network_fine", precision="fp16")
 
 
 def test_checkpoint_resumes_training_like_torch(tab):
