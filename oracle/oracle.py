@@ -4,7 +4,7 @@ numpy/ctypes front end of the CPU restatement in oracle/orc_sampling.c and oracl
 the orchestration of render_rays / render (render.py:134-315) and the MLP backward (numpy) used to
 check the HIP path's gradients.  Only tests/, __graft_entry__.smoke() and bench.py's
 `cpu_baseline` leg may import this module.  Parity with the reference is pinned by
-tests/golden/static.npz and tests/golden/dnerf.npz (see tests/test_oracle_golden.py).
+tests/golden/{static,dnerf,static2,dnerf2}.npz (see tests/test_oracle_golden.py, tests/test_oracle_golden2.py).
 """
 import ctypes as C
 import os
@@ -324,3 +324,66 @@ def build_rays(H, W, K, c2w=None, rays=None, ndc=False, near=0., far=1., use_vie
     if use_viewdirs:
         cols.append(vd)
     return np.ascontiguousarray(np.concatenate(cols, -1), dtype=np.float32)
+
+
+# ------------------------------------------------------------------ vanilla_dynamic variants (numpy, f64 internally)
+def _layernorm(h, w, b, eps=1e-5):
+    """nn.LayerNorm over the last axis (biased variance), as vanilla_dynamic/network.py:46-48 applies it."""
+    mu = h.mean(-1, keepdims=True)
+    var = ((h - mu) ** 2).mean(-1, keepdims=True)
+    return (h - mu) / np.sqrt(var + eps) * w + b
+
+
+def _trunk(sd, pre, names, x_in, x_skip, D, skips, ln_names=None):
+    """D x (Linear [+ LayerNorm] + ReLU) with cat[x_skip, h] after the layers in `skips` (network.py:73-79)."""
+    h = x_in
+    for i in range(D):
+        h = h @ sd[f"{pre}{names}.{i}.weight"].astype(np.float64).T + sd[f"{pre}{names}.{i}.bias"]
+        if ln_names is not None:
+            h = _layernorm(h, sd[f"{pre}{ln_names}.{i}.weight"], sd[f"{pre}{ln_names}.{i}.bias"])
+        h = np.maximum(h, 0)
+        if i in skips:
+            h = np.concatenate([x_skip, h], -1)
+    return h
+
+
+def _views_head(sd, pre, h, xv, layernorm):
+    """alpha / feature / view layer / rgb (network.py:81-93)."""
+    alpha = h @ sd[pre + "alpha_linear.weight"].astype(np.float64).T + sd[pre + "alpha_linear.bias"]
+    feat = h @ sd[pre + "feature_linear.weight"].astype(np.float64).T + sd[pre + "feature_linear.bias"]
+    hv = np.concatenate([feat, xv], -1) @ sd[pre + "views_linears.0.weight"].astype(np.float64).T \
+        + sd[pre + "views_linears.0.bias"]
+    if layernorm:
+        hv = _layernorm(hv, sd[pre + "views_layernorm.weight"], sd[pre + "views_layernorm.bias"])
+    hv = np.maximum(hv, 0)
+    rgb = hv @ sd[pre + "rgb_linear.weight"].astype(np.float64).T + sd[pre + "rgb_linear.bias"]
+    return np.concatenate([rgb, alpha], -1)
+
+
+def nerf_forward_np(sd, x, D=8, input_ch=63, skips=(4,), prefix="", layernorm=False):
+    """vanilla_dynamic NeRF.forward (network.py:60-97), optional LayerNorm, on embedded rows x [P, input_ch + views]."""
+    x = np.asarray(x, np.float64)
+    xp, xv = x[:, :input_ch], x[:, input_ch:]
+    h = _trunk(sd, prefix, "pts_linears", xp, xp, D, skips, "pts_layernorms" if layernorm else None)
+    return _views_head(sd, prefix, h, xv, layernorm).astype(np.float32)
+
+
+def deformation_forward_np(sd, pts, dirs, times, D=8, D_deform=8, skips=(4,), layernorm=False, multires=10,
+                           multires_views=4, multires_time=10):
+    """DNeRF_Deformation.forward for t != 0 (network.py:307-341) on raw points / directions / times [P,1]
+    -> (out [P,4], dx [P,3])."""
+    xe = embed(pts, multires).astype(np.float64)
+    te = embed(times, multires_time).astype(np.float64)
+    h = _trunk(sd, "", "_time", np.concatenate([xe, te], -1), xe, D_deform, skips,
+               "_time_layernorms" if layernorm else None)
+    dx = (h @ sd["_time_out.weight"].astype(np.float64).T + sd["_time_out.bias"]).astype(np.float32)
+    x2 = embed(_f(pts) + dx, multires)
+    xin = np.concatenate([x2, embed(dirs, multires_views)], -1)
+    return nerf_forward_np(sd, xin, D, xe.shape[1], skips, "_occ.", layernorm), dx
+
+
+def straightforward_forward_np(sd, pts, dirs, times, D=8, skips=(4,), multires=10, multires_views=4, multires_time=10):
+    """DNeRF_Straightforward.forward (network.py:151-196): trunk input and skip are cat[gamma(x), gamma(t)]."""
+    xt = np.concatenate([embed(pts, multires), embed(times, multires_time)], -1).astype(np.float64)
+    h = _trunk(sd, "", "pts_linears", xt, xt, D, skips)
+    return _views_head(sd, "", h, embed(dirs, multires_views).astype(np.float64), False).astype(np.float32)

@@ -4,6 +4,8 @@
     python tests/golden/make_golden.py static     -> tests/golden/static.npz
     python tests/golden/make_golden.py dnerf      -> tests/golden/dnerf.npz
     python tests/golden/make_golden.py tooling    -> tests/golden/tooling.npz + tests/golden/ref_ckpt_small.tar
+    python tests/golden/make_golden.py static2    -> tests/golden/static2.npz  (configs[0] at 100x100; output_ch = 5 nets)
+    python tests/golden/make_golden.py dnerf2     -> tests/golden/dnerf2.npz   (well-conditioned D-NeRF, LayerNorm, straightforward)
 
 The reference (a pure-Python/PyTorch project at /root/reference) cannot travel to the GPU box, so
 its outputs on seeded synthetic inputs are frozen here as data.  Inputs come from
@@ -468,7 +470,177 @@ def gen_tooling(out):
     print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), "and", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_static2(out):
+    """Round-2 additions, static stack: (1) BASELINE configs[0] at its own size -- render() of the 100x100 view,
+    default-init nets, theta = 0 (render.py:247-315); (2) model.py:26-41's no-viewdirs wiring
+    (output_ch = 5 when N_importance > 0, render.py:100-103 slices raw[..., :3] / raw[..., 3]) through render_rays with
+    a fine pass, and the parameter gradients of train.py:232-242's loss."""
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, REF)
+    import torch
+    import positional_encoding as pe
+    import network
+    import render as rr
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    T = torch.from_numpy
+    e10, _ = pe.get_embedder(10, 0)
+    e4, _ = pe.get_embedder(4, 0)
+
+    def query_fn(embed, embeddirs, chunk=65536):
+        return lambda inputs, viewdirs, fn: rr.run_network(inputs, viewdirs, fn, embed, embeddirs, chunk)
+
+    c_s = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(24))
+    f_s = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(25))
+    H = W = 100
+    K, focal = fx.intrinsics(H, W)
+    c2w = fx.pose_spherical(0.0, -30.0, 4.0)[:3, :4]
+    kw = dict(network_query_fn=query_fn(e10, e4), perturb=0., N_importance=128, network_fine=f_s, N_samples=64,
+              network_fn=c_s, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+    with torch.no_grad():
+        rgb, disp, acc, extras = rr.render(H, W, K, chunk=32768, c2w=T(c2w), near=2., far=6., **kw)
+    G["c1_c2w"], G["c1_K"] = c2w, K
+    G["c1_rgb"], G["c1_disp"], G["c1_acc"] = rgb.numpy(), disp.numpy(), acc.numpy()
+    G["c1_rgb0"], G["c1_acc0"], G["c1_z_std"] = extras["rgb0"].numpy(), extras["acc0"].numpy(), extras["z_std"].numpy()
+
+    # no view directions, output_ch = 5 (model.py:30: output_ch = 5 if N_importance > 0), fine pass through a second net
+    def mk(seed):
+        sd = fx.make_nerf_state(seed, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=5, skips=(2,),
+                                use_viewdirs=False)
+        return _load(torch, network.NeRF(4, 128, 63, 0, 5, [2], False), sd)
+    c5, f5 = mk(41), mk(42)
+    r8 = fx.blender_rays(40, 13, with_viewdirs=False)
+    tgt = np.random.RandomState(14).rand(40, 3).astype(np.float32)
+    ret = rr.render_rays(T(r8), c5, query_fn(e10, None), 64, retraw=True, N_importance=32, network_fine=f5,
+                         white_bkgd=True, perturb=0.)
+    loss = torch.mean((ret["rgb_map"] - T(tgt)) ** 2) + torch.mean((ret["rgb0"] - T(tgt)) ** 2)
+    loss.backward()
+    G["nv5_rays"], G["nv5_target"], G["nv5_loss"] = r8, tgt, np.array([loss.item()])
+    for k, v in ret.items():
+        G[f"nv5_{k}"] = v.detach().numpy()
+    for tag, net in (("coarse", c5), ("fine", f5)):
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                G[f"nv5_grad_{tag}_{k}"] = grad_summary(p.grad)
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
+def gen_dnerf2(out):
+    """Round-2 additions, vanilla_dynamic stack, all on WELL-CONDITIONED models (default-init family, dx_scale = 1), where
+    the reference's outputs are reproducible to the north star's 1e-4 end to end: render_rays_dnerf ret-dicts at t = 0.5
+    and per-ray times, a 100 x 100 render_dnerf image at t = 0.5 (BASELINE configs[4] at the size of configs[0]), the
+    training gradients, the LayerNorm variants (network.py:46-48, :75-76, :88-89, :276-300) forward and backward, and
+    DNeRF_Straightforward.forward (network.py:151-196; callable directly although run_network_dnerf cannot reach it)."""
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, os.path.join(REF, "vanilla_dynamic"))
+    import torch
+    import positional_encoding as pe
+    import network
+    import render as rr
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    T = torch.from_numpy
+    rng = np.random.RandomState(8765)
+    embed_fn, _ = pe.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = pe.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = pe.get_time_embedder(10)
+
+    def mk_model(sd, **kw):
+        m = network.DNeRF_Deformation(input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4,
+                                      use_viewdirs=True, zero_canonical=True, **kw)
+        m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+        m.embed_fn = embed_fn
+        return m
+
+    model = mk_model(fx.make_dnerf_state(33, peaky=False, dx_scale=1.0), D=8, W=256, D_deform=8, W_deform=256, skips=[4])
+    qfn = lambda inputs, viewdirs, times, fn: rr.run_network_dnerf(  # noqa: E731
+        inputs, viewdirs, times, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, embed_time_fn=embed_time,
+        netchunk=65536, network_type="deformation")
+    rays = fx.blender_rays(48, 15)
+    G["rr_rays"] = rays
+    with torch.no_grad():
+        ret = rr.render_rays_dnerf(T(rays), torch.full((48, 1), 0.5), model, qfn, 64, retraw=True, perturb=0.,
+                                   N_importance=128, network_fine=None, white_bkgd=True)
+        for k, v in ret.items():
+            G[f"rr_t05_{k}"] = v.numpy()
+        tv = T(rng.uniform(0.1, 1, (48, 1)).astype(np.float32))
+        ret = rr.render_rays_dnerf(T(rays), tv, model, qfn, 64, retraw=False, perturb=0., N_importance=128,
+                                   network_fine=None, white_bkgd=True)
+        G["rr_tvar_times"] = tv.numpy()
+        for k, v in ret.items():
+            G[f"rr_tvar_{k}"] = v.numpy()
+        H = W = 100
+        K, focal = fx.intrinsics(H, W)
+        c2w = fx.pose_spherical(0.0, -30.0, 4.0)[:3, :4]
+        rgb, disp, acc, extras = rr.render_dnerf(
+            H, W, K, 0.5, chunk=32768, c2w=T(c2w), near=2., far=6., use_viewdirs=True, network_fn=model,
+            network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None, white_bkgd=True,
+            raw_noise_std=0.)
+        G["img_c2w"], G["img_K"] = c2w, K
+        G["img_rgb"], G["img_disp"], G["img_acc"] = rgb.numpy(), disp.numpy(), acc.numpy()
+        G["img_rgb0"], G["img_acc0"] = extras["rgb0"].numpy(), extras["acc0"].numpy()
+        dxm = extras["dx"].numpy()
+        G["img_dx_absmax"] = np.abs(dxm).max(axis=(2, 3))      # [H, W]: per-pixel largest |dx| of the fine pass
+
+    # training gradients on the smooth model (train.py:238-276 minus clip/optimizer), incl. the dx regulariser (:252-260)
+    ro, rd, target = fx.train_batch(32, seed=6)
+    vd = rd / np.linalg.norm(rd, axis=-1, keepdims=True)
+    trays = np.concatenate([ro, rd, np.full((32, 1), 2, np.float32), np.full((32, 1), 6, np.float32), vd], -1).astype(np.float32)
+    tv = T(rng.uniform(0.1, 1, (32, 1)).astype(np.float32))
+    model.zero_grad()
+    ret = rr.render_rays_dnerf(T(trays), tv, model, qfn, 64, retraw=True, perturb=0., N_importance=128,
+                               network_fine=None, white_bkgd=True)
+    loss = torch.mean((ret["rgb_map"] - T(target)) ** 2) + torch.mean((ret["rgb0"] - T(target)) ** 2) \
+        + 0.1 * torch.mean(ret["dx"] ** 2)
+    loss.backward()
+    G["train_rays"], G["train_times"], G["train_target"] = trays, tv.numpy(), target
+    G["train_loss"] = np.array([loss.item()])
+    for k, p in model.named_parameters():
+        G[f"train_grad_{k}"] = grad_summary(p.grad)
+
+    # ---- LayerNorm variants
+    pts = rng.uniform(-1.5, 1.5, (320, 3)).astype(np.float32)
+    dirs = rng.normal(size=(320, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    tt = rng.uniform(0.05, 1, (320, 1)).astype(np.float32)
+    G["ln_pts"], G["ln_dirs"], G["ln_times"] = pts, dirs, tt
+    xin = torch.cat([embed_fn(T(pts)), embeddirs_fn(T(dirs))], -1)
+    for tag, D, W, skips in (("small", 3, 64, [1]), ("full", 8, 256, [4])):
+        sd = fx.make_dnerf_layernorm_state(51 if tag == "small" else 52, D=D, W=W, D_deform=D, W_deform=W, skips=tuple(skips))
+        m = mk_model(sd, D=D, W=W, D_deform=D, W_deform=W, skips=skips, use_layernorm=True)
+        with torch.no_grad():
+            o, z = m._occ(xin)
+            G[f"ln_{tag}_occ_out"] = o.numpy()
+        te = embed_time(T(tt))
+        m.zero_grad()
+        out_, dx = m(xin, [te, te], pts_raw=T(pts), t_raw=T(tt))
+        G[f"ln_{tag}_out"], G[f"ln_{tag}_dx"] = out_.detach().numpy(), dx.detach().numpy()
+        gw = rng.normal(size=(320, 4)).astype(np.float32)
+        gd = rng.normal(size=(320, 3)).astype(np.float32)
+        ((out_ * T(gw)).sum() + (dx * T(gd)).sum()).backward()
+        G[f"ln_{tag}_gw"], G[f"ln_{tag}_gd"] = gw, gd
+        for k, p in m.named_parameters():
+            G[f"ln_{tag}_grad_{k}"] = grad_summary(p.grad)
+
+    # ---- DNeRF_Straightforward.forward(x, ts)
+    sf = network.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4,
+                                       skips=[4], use_viewdirs=True)
+    sf.load_state_dict({k: T(v) for k, v in fx.make_straightforward_state(61).items()}, strict=True)
+    te = embed_time(T(tt))
+    out_, dx = sf(xin, [te, te])
+    G["sf_out"], G["sf_dx"] = out_.detach().numpy(), dx.detach().numpy()
+    gw = rng.normal(size=(320, 4)).astype(np.float32)
+    (out_ * T(gw)).sum().backward()
+    G["sf_gw"] = gw
+    for k, p in sf.named_parameters():
+        G[f"sf_grad_{k}"] = grad_summary(p.grad)
+
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
     {"static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest,
-     "tooling": gen_tooling}[which](os.path.join(HERE, f"{which}.npz"))
+     "tooling": gen_tooling, "static2": gen_static2, "dnerf2": gen_dnerf2}[which](os.path.join(HERE, f"{which}.npz"))

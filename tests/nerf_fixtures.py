@@ -74,6 +74,31 @@ def make_dnerf_state(seed, D=8, W=256, D_deform=8, W_deform=256, input_ch=63, in
     return sd
 
 
+def add_layernorm_state(sd, seed, prefix, names):
+    """LayerNorm parameters (vanilla_dynamic/network.py:46-48, :275-277) away from their (1, 0) init, so that a
+    kernel that dropped the affine part would be caught.  `names` = [(module name, width), ...]."""
+    rng = np.random.RandomState(seed)
+    for name, width in names:
+        sd[f"{prefix}{name}.weight"] = rng.uniform(0.5, 1.5, size=(width,)).astype(np.float32)
+        sd[f"{prefix}{name}.bias"] = rng.uniform(-0.2, 0.2, size=(width,)).astype(np.float32)
+    return sd
+
+
+def make_dnerf_layernorm_state(seed, D=8, W=256, D_deform=8, W_deform=256, skips=(4,), dx_scale=1.0):
+    """state_dict of DNeRF_Deformation(use_layernorm=True): make_dnerf_state + `_occ.pts_layernorms.*`,
+    `_occ.views_layernorm.*`, `_time_layernorms.*`."""
+    sd = make_dnerf_state(seed, D=D, W=W, D_deform=D_deform, W_deform=W_deform, skips=skips, dx_scale=dx_scale)
+    add_layernorm_state(sd, seed + 101, "_occ.", [(f"pts_layernorms.{i}", W) for i in range(D)] + [("views_layernorm", W // 2)])
+    add_layernorm_state(sd, seed + 202, "", [(f"_time_layernorms.{i}", W_deform) for i in range(D_deform)])
+    return sd
+
+
+def make_straightforward_state(seed, D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, skips=(4,)):
+    """state_dict of DNeRF_Straightforward (vanilla_dynamic/network.py:135-149): the NeRF layout with
+    gamma(x) ++ gamma(t) as the trunk input (and as the skip)."""
+    return make_nerf_state(seed, D, W, input_ch + input_ch_time, input_ch_views, 4, skips, True)
+
+
 def pose_spherical(theta_deg, phi_deg, radius):
     """Camera-to-world 4x4 on a sphere looking at the origin (formula of load_blender.py:10-34)."""
     th, ph = theta_deg / 180.0 * np.pi, phi_deg / 180.0 * np.pi
