@@ -91,6 +91,11 @@ int nrf_points(const float *rays, int64_t n_rays, int32_t ncol, const float *z_v
 int nrf_pe_fwd(const float *x, int64_t n_points, int32_t dims, int32_t num_freqs, float max_freq_log2,
                int32_t log_sampling, int32_t include_input, float *out, void *stream);
 
+/* autograd of A1 w.r.t. x -- what loss.backward() computes through embed_fn(pts + dx) on the D-NeRF path
+ * (vanilla_dynamic/network.py:331-333).  g_out [P, out_dim] -> g_x [P, dims]. */
+int nrf_pe_bwd(const float *x, const float *g_out, int64_t n_points, int32_t dims, int32_t num_freqs,
+               float max_freq_log2, int32_t log_sampling, int32_t include_input, float *g_x, void *stream);
+
 /* K2+K3 weights: nn.Linear layout -> the MFMA-fragment-ordered layout the query kernels stream.
  * nrf_mlp_packed_floats returns the number of floats `packed` must hold (<= 0: unsupported shape). */
 int64_t nrf_mlp_packed_floats(const nrf_net_t *net, const nrf_embed_t *emb);

@@ -35,6 +35,7 @@ _SIGS = {
     "nrf_sample_coarse": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
     "nrf_points": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp]),
     "nrf_pe_fwd": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, vp, vp]),
+    "nrf_pe_bwd": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, vp, vp]),
     "nrf_mlp_packed_floats": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_mlp_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_query_fwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),

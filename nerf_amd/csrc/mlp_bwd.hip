@@ -589,8 +589,8 @@ struct Bwd {
 
 using namespace nrf;
 
-static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles) {
-    int64_t nchunks = ntiles < 256 ? ntiles : 256;
+static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles, int max_chunks = 256) {
+    int64_t nchunks = ntiles < max_chunks ? ntiles : max_chunks;
     *chunk_tiles = (int)((ntiles + nchunks - 1) / nchunks);
     return (ntiles + *chunk_tiles - 1) / *chunk_tiles;
 }
@@ -601,21 +601,23 @@ extern "C" int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points
     return ((n_points + 31) / 32) * tl.g_tile;
 }
 
-extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points) {
+static int64_t slab_floats(const nrf_net_t *net, int64_t n_points, int max_chunks) {
     if (!net || net->W % 32 || n_points < 0) return -1;
     int ct;
-    int64_t nchunks = pick_chunks((n_points + 31) / 32, &ct);
+    int64_t nchunks = pick_chunks((n_points + 31) / 32, &ct, max_chunks);
     // every GEMM of the pass (<= D trunk layers + 3 heads) keeps its own slab region; bound on each:
     // (feature + alpha row) x cat[hidden, gamma(x), gamma(t)]
     int64_t np = net->W + 32, kp = net->W + 2 * kKsX + 32;
     return nchunks * (net->D + 3) * (np * kp + np);
 }
 
+extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points) { return slab_floats(net, n_points, 256); }
+
 // time_ch > 0: `net` describes a deformation ("time") net (layer 0 also reads gamma(t)).  pts/g_pts non-null: also
 // return d(loss)/d(pts) (canonical nets with the fused encoding).
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
-                          const nrf_net_t *grads, const float *pts, float *g_pts, void *stream) {
+                          const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
@@ -659,8 +661,8 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     Bwd B{};
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
     B.ntiles = ntiles; B.st = st;
-    B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles);
-    B.slab_cap = nrf_train_slab_floats(net, n_points);
+    B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, max_chunks);
+    B.slab_cap = slab_floats(net, n_points, max_chunks);
     const TrainLayout &tl = d.tl;
     const int xk = 2 * kKsX / 32, dk = 2 * kKsD / 32;  // 32-channel tiles of the k-space input blocks
     const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};
@@ -730,3 +732,4 @@ extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *
     return query_bwd_impl(time_net, emb, time_net->input_ch_views, packed_time, g_dx, acts, gbuf, slab, n_points, grads,
                           nullptr, nullptr, stream);
 }
+

@@ -29,6 +29,7 @@ class _QueryFunction(torch.autograd.Function):
         if need_grad:
             raw, acts = packed.query_train(pts, viewdirs, pts_per_ray)
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
+            ctx.versions = packed._versions     # the dgrad chain reads the packed copy: it must still be this one
             ctx.save_for_backward(acts)
             return raw
         return packed.query(pts, viewdirs, pts_per_ray)
@@ -37,6 +38,11 @@ class _QueryFunction(torch.autograd.Function):
     def backward(ctx, g_raw):
         (acts,) = ctx.saved_tensors
         packed = ctx.module._packed(ctx.key)
+        if packed._versions != ctx.versions:
+            # torch autograd raises the same way when a tensor saved for backward was modified in place
+            raise RuntimeError("nerf_amd: a parameter of this network was modified (optimizer.step(), load_state_dict) "
+                               "between the forward and this backward; the packed weights no longer match the saved "
+                               "activations")
         grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts)
         order = [name for name, _ in ctx.module.named_parameters()]
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in order)
@@ -99,18 +105,41 @@ class NeRF(nn.Module):
         if not torch.is_grad_enabled():
             return False
         if x is not None and x.requires_grad:
-            # the backward kernels produce PARAMETER gradients only; refusing beats silently dropping d/dx
-            raise NotImplementedError("nerf_amd: gradients w.r.t. the network INPUT are not built (only parameter "
-                                      "gradients); detach the input or run under torch.no_grad()")
+            # the fused query's backward produces PARAMETER gradients only (nrf_query_bwd_input adds d/d(pts) for the
+            # deformation chain); refusing beats silently dropping d/dx
+            raise NotImplementedError("nerf_amd: gradients w.r.t. the query points are not built for this call "
+                                      "(only parameter gradients); detach the input or run under torch.no_grad()")
         return any(p.requires_grad for p in self.parameters())
+
+    def _forward_autograd(self, x):
+        """network.py:46-69 composed from torch ops ON THE GPU: taken only when the caller needs d(out)/d(x) of
+        already-embedded rows (D-NeRF training with a non-standard embedder re-embeds pts + dx outside the fused
+        chain, vanilla_dynamic/network.py:331-339); autograd then covers what the reference's does."""
+        F = torch.nn.functional
+        input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = input_pts
+        for i in range(self.D):
+            h = F.relu(self.pts_linears[i](h))
+            if i in self.skips:
+                h = torch.cat([input_pts, h], -1)
+        if not self.use_viewdirs:
+            return self.output_linear(h)
+        alpha = self.alpha_linear(h)
+        h = torch.cat([self.feature_linear(h), input_views], -1)
+        h = F.relu(self.views_linears[0](h))
+        return torch.cat([self.rgb_linear(h), alpha], -1)
 
     def _params_in_order(self):
         return [p for _, p in self.named_parameters()]
 
     # ------------------------------------------------------------------ queries
     def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("nerf_amd.NeRF.forward: input is on the CPU; nerf_amd has no CPU path")
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
+        if torch.is_grad_enabled() and x2.requires_grad:
+            return self._forward_autograd(x2).reshape(*lead, -1)
         out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, self._need_grad(x2), *self._params_in_order())
         return out.reshape(*lead, out.shape[-1])
 

@@ -148,7 +148,17 @@ def pe_fwd(x, num_freqs, max_freq_log2, log_sampling=True, include_input=True):
 
 
 def pe_bwd(x, g_out, num_freqs, max_freq_log2, log_sampling=True, include_input=True):
-    raise NotImplementedError("nrf_pe_bwd is not built yet")
+    """d(loss)/dx from d(loss)/d(gamma(x))."""
+    x, g_out = _f32(x, "x"), _f32(g_out, "g_out")
+    dims = x.shape[-1]
+    flat = x.reshape(-1, dims)
+    od = dims * ((1 if include_input else 0) + 2 * num_freqs)
+    g2 = g_out.reshape(-1, od)
+    assert g2.shape[0] == flat.shape[0]
+    g_x = torch.empty_like(flat)
+    check(_lib.lib().nrf_pe_bwd(_ptr(flat), _ptr(g2), flat.shape[0], dims, num_freqs, float(max_freq_log2),
+                                int(log_sampling), int(include_input), _ptr(g_x), _stream()), "nrf_pe_bwd")
+    return g_x.reshape(x.shape)
 
 
 # ---------------------------------------------------------------- compositing
@@ -164,7 +174,9 @@ def _dirs(rays_d):
 def composite_fwd(raw, z_vals, rays_d, noise=None, white_bkgd=False):
     raw, z_vals = _f32(raw, "raw"), _f32(z_vals, "z_vals")
     N, S = z_vals.shape
-    assert raw.shape == (N, S, 4), f"raw must be [N,S,4], got {tuple(raw.shape)}"
+    if raw.shape != (N, S, 4):
+        raise ValueError(f"composite_fwd: raw must be [N,S,4] = {(N, S, 4)}, got {tuple(raw.shape)} "
+                         "(raw2outputs slices wider network outputs, render.py:100-103)")
     d, ds = _dirs(rays_d)
     assert d.shape[0] == N
     dev = raw.device

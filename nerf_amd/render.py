@@ -105,6 +105,10 @@ class _CompositeFunction(torch.autograd.Function):
 
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
     """[N,S,4] raw predictions -> (rgb_map [N,3], disp_map [N], acc_map [N], weights [N,S], depth_map [N])."""
+    if raw.shape[-1] > 4:
+        # model.py:30 builds output_ch = 5 nets when N_importance > 0 and the reference reads raw[..., :3] and
+        # raw[..., 3] only (render.py:100-103); autograd returns zeros for the channels left out
+        raw = raw[..., :4]
     noise = None
     if raw_noise_std > 0.:
         if pytest:  # the reference's fixed-random route draws UNIFORM numbers here (render.py:114-117)

@@ -7,7 +7,9 @@
 State_dict keys are the reference's (`_occ.*`, `_time.{i}.*`, `_time_out.*`, `pts_layernorms.*`, ...).
 DNeRF_Deformation runs as ONE fused HIP kernel (nrf_dnerf_query_fwd) whenever the inputs allow it: raw
 points / raw time available (run_network_dnerf always passes them), standard embedders, no LayerNorm.
-Training through the deformation chain is not built yet in this round: calls that need gradients raise.
+Training goes through `_DeformFunction`: time-net forward with saved activations -> x + dx -> canonical forward-train;
+backward = nrf_query_bwd_input (canonical parameter gradients + d/d(x + dx)) -> nrf_dnerf_time_bwd.  Configurations
+outside the fused kernels (LayerNorm, non-standard embedders) are composed from GPU torch ops + nrf_pe_fwd/_bwd.
 """
 import ctypes as C
 
@@ -37,6 +39,7 @@ class _DeformFunction(torch.autograd.Function):
         x2 = pts + dx
         raw, acts_c = occ.query_train(x2, viewdirs, pts_per_ray)
         ctx.module, ctx.keys, ctx.n_points = module, (L, Lv, Lt), P
+        ctx.versions = (tnet._versions, occ._versions)
         ctx.save_for_backward(acts_t, acts_c, x2, skip)
         ctx.set_materialize_grads(False)
         return raw, dx
@@ -47,6 +50,9 @@ class _DeformFunction(torch.autograd.Function):
         module, (L, Lv, Lt) = ctx.module, ctx.keys
         occ = module._occ._packed((0, L, Lv))
         tnet = module._time_packed(L, Lt)
+        if (tnet._versions, occ._versions) != ctx.versions:
+            raise RuntimeError("nerf_amd: a parameter of this network was modified between the forward and this backward; "
+                               "the packed weights no longer match the saved activations")
         if g_raw is None:
             g_raw = torch.zeros((ctx.n_points, 4), device=x2.device)
         g_occ, g_x2 = occ.query_bwd(g_raw.contiguous(), ctx.n_points, acts_c, pts=x2)
@@ -64,6 +70,17 @@ class _DeformFunction(torch.autograd.Function):
             else:
                 out.append(None)
         return (None,) * 10 + tuple(out)
+
+
+def _layer_norm(h, ln):
+    """nn.LayerNorm(W) (vanilla_dynamic/network.py:46-48, :276-277) from elementwise ops and two row reductions.
+    The module `ln` only holds the parameters (state_dict keys): torch-ROCm's fused LayerNorm BACKWARD kernel was
+    measured 8e-3 off in f32 on gfx950 (gradient norms against the reference's CPU autograd and against the same graph in
+    f64; this composition: 2e-5), which would break gradient parity of the use_layernorm configurations."""
+    mu = h.mean(-1, keepdim=True)
+    d = h - mu
+    var = (d * d).mean(-1, keepdim=True)
+    return d / torch.sqrt(var + ln.eps) * ln.weight + ln.bias
 
 
 class NeRF(_StaticNeRF):
@@ -94,14 +111,14 @@ class NeRF(_StaticNeRF):
         input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
         h = input_pts
         for i in range(self.D):
-            h = F.relu(self.pts_layernorms[i](self.pts_linears[i](h)))
+            h = F.relu(_layer_norm(self.pts_linears[i](h), self.pts_layernorms[i]))
             if i in self.skips:
                 h = torch.cat([input_pts, h], -1)
         if not self.use_viewdirs:
             return self.output_linear(h)
         alpha = self.alpha_linear(h)
         h = torch.cat([self.feature_linear(h), input_views], -1)
-        h = F.relu(self.views_layernorm(self.views_linears[0](h)))
+        h = F.relu(_layer_norm(self.views_linears[0](h), self.views_layernorm))
         return torch.cat([self.rgb_linear(h), alpha], -1)
 
 
@@ -355,7 +372,7 @@ class DNeRF_Deformation(nn.Module):
             for i in range(self.D_deform):
                 h = self._time[i](h)
                 if self._time_layernorms is not None:
-                    h = self._time_layernorms[i](h)
+                    h = _layer_norm(h, self._time_layernorms[i])
                 h = F.relu(h)
                 if i in self.skips_deform:
                     h = torch.cat([input_pts, h], -1)

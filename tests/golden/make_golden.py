@@ -502,6 +502,23 @@ def gen_static2(out):
     G["c1_c2w"], G["c1_K"] = c2w, K
     G["c1_rgb"], G["c1_disp"], G["c1_acc"] = rgb.numpy(), disp.numpy(), acc.numpy()
     G["c1_rgb0"], G["c1_acc0"], G["c1_z_std"] = extras["rgb0"].numpy(), extras["acc0"].numpy(), extras["z_std"].numpy()
+    # the SAME reference code run in float64 (torch.set_default_dtype): what the algorithm computes without f32 rounding.
+    # |f32 run - f64 run| is the reference's own rounding error on this view -- the fine pass amplifies 1e-7 differences of
+    # the coarse weights through sample_pdf on near-empty rays -- and bounds what "agrees with the reference" can mean.
+    torch.set_default_dtype(torch.float64)
+    try:
+        c64 = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True).double(),
+                    {k: v.astype(np.float64) for k, v in fx.make_nerf_state(24).items()})
+        f64 = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True).double(),
+                    {k: v.astype(np.float64) for k, v in fx.make_nerf_state(25).items()})
+        kw64 = dict(kw, network_fn=c64, network_fine=f64)
+        with torch.no_grad():
+            rgb64, disp64, acc64, _ = rr.render(H, W, K, chunk=32768, c2w=T(c2w).double(), near=2., far=6., **kw64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    G["c1_rgb_f64"], G["c1_disp_f64"], G["c1_acc_f64"] = rgb64.numpy(), disp64.numpy(), acc64.numpy()
+    for k in ("rgb", "disp", "acc"):
+        print(f"c1 {k}: |reference f32 - reference f64| max = {np.abs(G['c1_' + k] - G['c1_' + k + '_f64']).max():.3e}")
 
     # no view directions, output_ch = 5 (model.py:30: output_ch = 5 if N_importance > 0), fine pass through a second net
     def mk(seed):
@@ -580,8 +597,36 @@ def gen_dnerf2(out):
         G["img_c2w"], G["img_K"] = c2w, K
         G["img_rgb"], G["img_disp"], G["img_acc"] = rgb.numpy(), disp.numpy(), acc.numpy()
         G["img_rgb0"], G["img_acc0"] = extras["rgb0"].numpy(), extras["acc0"].numpy()
-        dxm = extras["dx"].numpy()
-        G["img_dx_absmax"] = np.abs(dxm).max(axis=(2, 3))      # [H, W]: per-pixel largest |dx| of the fine pass
+        G["img_dx_absmean"] = np.abs(extras["dx"].numpy()).mean(axis=(2, 3))      # [H, W]: per-pixel mean |dx|, fine pass
+    # the last sample's density, fine and coarse pass (its alpha is a step function of the sign: render.py:98), for the
+    # bf16 test's stability mask
+    with torch.no_grad():
+        ret = rr.render_dnerf(H, W, K, 0.5, chunk=32768, c2w=T(c2w), near=2., far=6., use_viewdirs=True, network_fn=model,
+                              network_query_fn=qfn, N_samples=64, perturb=0., N_importance=0, network_fine=None,
+                              white_bkgd=True, raw_noise_std=0., retraw=True)[3]
+        G["img_raw0_last_sigma"] = ret["raw"][..., -1, 3].numpy()
+        ret = rr.render_dnerf(H, W, K, 0.5, chunk=32768, c2w=T(c2w), near=2., far=6., use_viewdirs=True, network_fn=model,
+                              network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+                              white_bkgd=True, raw_noise_std=0., retraw=True)[3]
+        G["img_raw_last_sigma"] = ret["raw"][..., -1, 3].numpy()
+    torch.set_default_dtype(torch.float64)       # the same reference code in float64: see gen_static2
+    try:
+        m64 = network.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                        input_ch_time=21, output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+        m64.load_state_dict({k: T(v.astype(np.float64)) for k, v in fx.make_dnerf_state(33, peaky=False, dx_scale=1.0).items()},
+                            strict=True)
+        m64 = m64.double()
+        m64.embed_fn = embed_fn
+        with torch.no_grad():
+            rgb64, disp64, acc64, _ = rr.render_dnerf(
+                H, W, K, 0.5, chunk=32768, c2w=T(c2w).double(), near=2., far=6., use_viewdirs=True, network_fn=m64,
+                network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None, white_bkgd=True,
+                raw_noise_std=0.)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    G["img_rgb_f64"], G["img_disp_f64"], G["img_acc_f64"] = rgb64.numpy(), disp64.numpy(), acc64.numpy()
+    for k in ("rgb", "disp", "acc"):
+        print(f"dnerf img {k}: |reference f32 - reference f64| max = {np.abs(G['img_' + k] - G['img_' + k + '_f64']).max():.3e}")
 
     # training gradients on the smooth model (train.py:238-276 minus clip/optimizer), incl. the dx regulariser (:252-260)
     ro, rd, target = fx.train_batch(32, seed=6)
