@@ -136,6 +136,18 @@ int nrf_query_bwd_input(const nrf_net_t *net, const nrf_embed_t *emb, const floa
                         const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                         const float *pts, float *g_pts, void *stream);
 
+/* Allocation-free variant of nrf_query_bwd.  NO counterpart in the reference: it exists for callers that cannot allocate
+ * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same inputs, outputs
+ * and kernels as nrf_query_bwd, but `gbuf` and `slab` live in a 64 MiB file-scope device array inside the library (each GPU
+ * the library runs on holds its copy until the process ends) and the wgrad reduction uses <= 8 partial slabs per GEMM
+ * instead of <= 256, so the results agree with nrf_query_bwd's to f32 summation order (1e-5 of a gradient's scale), not
+ * bit for bit.  Limit: nrf_train_grads_floats(net, n) + 8-chunk slabs must fit the array -- 2048 points at D = 8,
+ * W = 256 (the error string of a refused call states the limit for the given network); larger passes use nrf_query_bwd.
+ * Calls no hipMalloc / hipFree.  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
+ * threads) race; serialise them. */
+int nrf_query_bwd_static(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                         const float *acts, int64_t n_points, const nrf_net_t *grads, void *stream);
+
 /* ---- D-NeRF deformation chain (vanilla_dynamic/) ----
  * The time ("deformation") net of DNeRF_Deformation (vanilla_dynamic/network.py:254-305) is described with
  * nrf_net_t as: pts_w/pts_b = the `_time` layers, out_w/out_b = `_time_out` (W -> 3), input_ch = position

@@ -46,6 +46,8 @@ _SIGS = {
                                       vp, vp]),
     "nrf_query_bwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
                                 C.POINTER(NrfNet), vp]),
+    "nrf_query_bwd_static": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.POINTER(NrfNet),
+                                       vp]),
     "nrf_dnerf_time_packed_floats": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_dnerf_pack_time_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_dnerf_query_fwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp,

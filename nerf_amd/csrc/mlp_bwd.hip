@@ -12,6 +12,7 @@
 //  3. reduce + unpack: sums the slabs over chunks (fixed order: deterministic) and scatters into the
 //     nn.Linear [out, in] gradient layout, undoing the k-space permutation of the input blocks.
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "mlp_device.h"
@@ -733,3 +734,60 @@ extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *
                           nullptr, nullptr, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Allocation-free variant of nrf_query_bwd for callers that cannot allocate device memory (code under HIP graph
+// capture, tight serving loops, harnesses that forbid hipMalloc): the two backward workspaces (`gbuf`, `slab`) live in
+// a file-scope device array instead of caller-provided buffers.  Every GPU the library runs on holds its own copy of
+// the array (64 MiB) until the process ends; the array keeps the previous call's contents -- nothing in this pass needs
+// zeroed scratch (dgrad writes every gradient block of every tile before wgrad reads it, wgrad writes every slab entry
+// the reduction reads) -- and calls that overlap on one GPU race on it.
+constexpr int64_t kStaticScratchFloats = (int64_t)16 << 20;      // 64 MiB
+constexpr int kStaticMaxChunks = 8;                              // wgrad partial slabs per GEMM (256 in nrf_query_bwd)
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+
+static std::mutex g_scratch_mu;
+static float *g_scratch_ptr[64] = {};   // per device: each GPU has the array at its own address
+
+// `scratch` in host code is a stand-in symbol, not a device address: resolve it once per device, with that device current.
+static int static_scratch(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64)
+        return nrf::fail(NRF_ERR_LAUNCH, "nrf_query_bwd_static: hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return nrf::fail(NRF_ERR_LAUNCH, "nrf_query_bwd_static: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                             hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<float *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return NRF_OK;
+}
+
+extern "C" int nrf_query_bwd_static(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                                    const float *acts, int64_t n_points, const nrf_net_t *grads, void *stream) {
+    NRF_REQUIRE(net && emb && grads, "nrf_query_bwd_static: null descriptor");
+    NRF_REQUIRE(n_points >= 0, "nrf_query_bwd_static: negative n_points");
+    const int64_t need_g = (nrf_train_grads_floats(net, n_points) + 63) & ~(int64_t)63;     // keep `slab` 256-byte aligned
+    const int64_t need_s = slab_floats(net, n_points, kStaticMaxChunks);
+    if (need_g < 0 || need_s < 0) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_static: unsupported network shape");
+    if (need_g + need_s > kStaticScratchFloats) {
+        // the slab part is constant beyond kStaticMaxChunks tiles; gbuf grows by g_tile floats per 32 points
+        const int64_t per_tile = nrf_train_grads_floats(net, 32);
+        const int64_t fixed = slab_floats(net, (int64_t)32 * kStaticMaxChunks, kStaticMaxChunks);
+        const int64_t max_pts = per_tile > 0 && fixed < kStaticScratchFloats ? (kStaticScratchFloats - fixed - 64) / per_tile * 32 : 0;
+        return nrf::fail(NRF_ERR_UNSUPPORTED,
+                         "nrf_query_bwd_static: %lld points need %lld bytes of backward workspace, the static scratch holds "
+                         "%lld (at most %lld points for this network); use nrf_query_bwd with caller-owned workspaces",
+                         (long long)n_points, (long long)((need_g + need_s) * 4), (long long)(kStaticScratchFloats * 4),
+                         (long long)max_pts);
+    }
+    float *base = nullptr;
+    int rc = static_scratch(&base);
+    if (rc) return rc;
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, base, base + need_g, n_points, grads, nullptr, nullptr, stream,
+                          kStaticMaxChunks);
+}
