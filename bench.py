@@ -115,6 +115,21 @@ def pmc_traffic(workload, kernel):
         return None
 
 
+def pmc_mfma_util(workload, kernel):
+    """Matrix-pipe busy fraction and held shader clock of `kernel` from the committed SQ pass (profiles/*_mfma_util.json,
+    latest round; scripts/profile_gpu.sh sq_all -> scripts/collect_profiles.py).  {} when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
+    if not files:
+        return {}
+    try:
+        e = json.load(open(files[-1]))[workload][kernel]
+        return {"mfma_busy_frac": round(e["mfma_busy_frac"], 4), "clock_ghz": round(e.get("clock_ghz", 0.0), 3),
+                "mfma_util_source": os.path.basename(files[-1])}
+    except (KeyError, ValueError):
+        return {}
+
+
 def hbm_kernels(torch, device, n_rays=32768, reps=20):
     """Achieved GB/s of the sampling / compositing kernels at the render chunk size: algorithmic bytes per launch
     (inputs read once + outputs written once) over the HIP-event duration, `reps` back-to-back launches."""
@@ -370,6 +385,10 @@ def main():
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": q_pts / max(q_n, 1),
                          "query_share_of_step": q_ms * 1e-3 / dt},
         }
+        out["roofline"].update(pmc_mfma_util("render_bf16" if bf16 else ("render_bf16x3" if x3 else "render"),
+                                             "query_fwd_bf16_kernel<8, true>" if bf16
+                                             else ("query_fwd_bf16x3_kernel<8, true>" if x3
+                                                   else "query_fwd_kernel<8, false, false, false>")))
         out["hbm_kernels"] = hbm_kernels(torch, device)
         if world == 1 and not args.no_extras and args.workload == "render" and not bf16 and not x3:
             out["also"] = extras(args, torch, dist, device, coarse, fine, step, timer)

@@ -12,6 +12,40 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def mfma_util(src, dst, rnd):
+    """profiles/<round>_mfma_util.json from the `sq_all` passes of scripts/profile_gpu.sh: per MFMA kernel
+      mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES)   (MFMA_BUSY counts cycles, WAVE_CYCLES quad-cycles;
+                       all of these kernels run one wave per SIMD, so wave time == SIMD time)
+      clock_ghz      = GRBM_GUI_ACTIVE / 8 / duration                     (the counter sums the 8 XCDs; MI355X_MICROARCH.md)
+      mfma_mops      = SQ_INSTS_VALU_MFMA_MOPS_{F32,BF16} per launch."""
+    util = {"_note": "one rocprofv3 --pmc pass per workload (7 SQ counters + GRBM_GUI_ACTIVE), scripts/profile_gpu.sh sq_all; "
+                     "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration; "
+                     "profiled passes run slower than un-profiled ones (counter collection serialises launches)"}
+    for w in ("render", "render_bf16", "render_bf16x3", "train", "dnerf", "dnerf_bf16"):
+        p = os.path.join(src, f"pmc_{w}_sq.summary.json")
+        if not os.path.exists(p):
+            continue
+        shutil.copy(p, os.path.join(dst, f"{rnd}_pmc_{w}_sq.summary.json"))
+        per = {}
+        for k, v in json.load(open(p)).items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in v or v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] <= 0:
+                continue
+            g = lambda c: v[c]["per_launch"] if c in v else None  # noqa: E731
+            e = {"launches": v["SQ_WAVE_CYCLES"]["launches"],
+                 "mfma_busy_frac": g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * g("SQ_WAVE_CYCLES")),
+                 "mfma_mops_f32": g("SQ_INSTS_VALU_MFMA_MOPS_F32"), "mfma_mops_bf16": g("SQ_INSTS_VALU_MFMA_MOPS_BF16")}
+            if "_duration_ns" in v and g("GRBM_GUI_ACTIVE"):
+                e["duration_ms"] = v["_duration_ns"]["per_launch"] * 1e-6
+                e["clock_ghz"] = g("GRBM_GUI_ACTIVE") / 8.0 / v["_duration_ns"]["per_launch"]
+            per[k.replace("nrf::", "").strip()] = e
+        if per:
+            util[w] = per
+    if len(util) > 1:
+        with open(os.path.join(dst, f"{rnd}_mfma_util.json"), "w") as f:
+            json.dump(util, f, indent=1, sort_keys=True)
+        print(json.dumps(util, indent=1, sort_keys=True)[:4000])
+
+
 def main(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
@@ -47,6 +81,9 @@ def main(tag, rnd):
             # steps executed by the profiled command (scripts/profile_gpu.sh: render 0+1, train 1+1, dnerf 0+1)
             per["_steps_profiled"] = {"render": 1, "train": 2, "dnerf": 1, "render_bf16": 1, "render_bf16x3": 1}[w]
             traffic[w] = per
+    mfma_util(src, dst, rnd)
+    if len(traffic) == 1:        # an SQ-only run: leave the traffic file of the round alone
+        return
     out_path = os.path.join(dst, f"{rnd}_pmc_traffic.json")
     if os.path.exists(out_path):
         old = json.load(open(out_path))

@@ -27,6 +27,18 @@ for what in "$@"; do
       done ;;
     sq)   # SQ_COUNTERS="A B C" (<= 8 SQ counters), EXTRA="--precision bf16" etc.
       timeout -s KILL 240 rocprofv3 --pmc $SQ_COUNTERS --output-format csv -d "$OUT/pmc_render_sq" -o render -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > "$OUT/pmc_render_sq.log" 2>&1 ;;
+    sq_all)   # MFMA-utilisation evidence: ONE pass (7 SQ + 1 GRBM counters) per workload; scripts/collect_profiles.py
+              # turns them into profiles/<round>_mfma_util.json (matrix-pipe busy fraction, held shader clock)
+      SQC="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+      for P in fp32 bf16 bf16x3; do
+        W=render_$P; [ $P = fp32 ] && W=render
+        timeout -s KILL 240 rocprofv3 --pmc $SQC --output-format csv -d "$OUT/pmc_${W}_sq" -o $W -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --precision $P > "$OUT/pmc_${W}_sq.log" 2>&1
+      done
+      timeout -s KILL 240 rocprofv3 --pmc $SQC --output-format csv -d "$OUT/pmc_train_sq" -o train -- python3 $ROOT/bench.py --workload train --steps 2 --warmup 1 > "$OUT/pmc_train_sq.log" 2>&1
+      for P in fp32 bf16; do
+        W=dnerf_$P; [ $P = fp32 ] && W=dnerf
+        timeout -s KILL 240 rocprofv3 --pmc $SQC --output-format csv -d "$OUT/pmc_${W}_sq" -o $W -- python3 $ROOT/bench.py --workload dnerf --steps 1 --warmup 0 --precision $P > "$OUT/pmc_${W}_sq.log" 2>&1
+      done ;;
     stats_bf16|stats_bf16x3)
       P=${what#stats_}
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_render_$P" -o render_$P -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision $P > "$OUT/render_${P}_stats.log" 2>&1 ;;

@@ -115,7 +115,9 @@ def test_render_rays_dnerf(gold_dnerf, parts, name):
     np.testing.assert_allclose(host(ret["rgb0"]), G[f"rr_{name}_rgb0"], atol=tol0, rtol=0)
     np.testing.assert_allclose(host(ret["acc0"]), G[f"rr_{name}_acc0"], atol=tol0, rtol=0)
     for k in ("rgb_map", "acc_map", "z_std"):
-        assert_mostly_close(host(ret[k]), G[f"rr_{name}_{k}"], what=f"{name} {k}", atol=1e-3, frac=0.7, hard=0.5)
+        # measured (MI355X, sharp dx_scale-3 fixture): every ray within 3.5e-4, PSNR >= 82.7 dB
+        assert_mostly_close(host(ret[k]), G[f"rr_{name}_{k}"], what=f"{name} {k}", atol=5e-4, frac=0.98, hard=1e-3,
+                            psnr_min=78.0)
     assert ret["dx"].shape == (48, 192, 3)
 
 
@@ -131,8 +133,9 @@ def test_render_dnerf_from_pose(gold_dnerf, parts):
                                         c2w=dev(G["render_c2w"]), near=2., far=6., use_viewdirs=True, **kw)
     assert rgb.shape == (8, 8, 3) and disp.shape == (8, 8) and extras["dx"].shape == (8, 8, 192, 3)
     assert torch.equal(rgb, rgb2)      # chunking and scalar-vs-tensor time do not change the result
-    assert_mostly_close(host(rgb), G["render_rgb"], what="rgb", atol=1e-3, frac=0.7, hard=0.5)
-    assert_mostly_close(host(acc), G["render_acc"], what="acc", atol=1e-3, frac=0.7, hard=0.5)
+    # measured: rgb 1.9e-4, acc 3.3e-4 at worst, PSNR 91.0 / 85.8 dB
+    assert_mostly_close(host(rgb), G["render_rgb"], what="rgb", atol=5e-4, frac=0.98, hard=1e-3, psnr_min=80.0)
+    assert_mostly_close(host(acc), G["render_acc"], what="acc", atol=5e-4, frac=0.98, hard=1e-3, psnr_min=80.0)
 
 
 def test_netchunk_t0_quirk(parts):

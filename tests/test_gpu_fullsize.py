@@ -101,8 +101,9 @@ def test_full_view_pixel_sample_vs_oracle(lego):
     coarse weight move a few rays' fine samples, so the bar is conftest.assert_mostly_close's."""
     from conftest import assert_mostly_close
     ys, xs, want = _oracle_sample(lego["K"], lego["c2w"], (21, 22), True)
-    assert_mostly_close(lego["rgb"][ys, xs].cpu().numpy(), want["rgb_map"], what="rgb")
-    assert_mostly_close(lego["acc"][ys, xs].cpu().numpy(), want["acc_map"], what="acc")
+    # measured: 98.5 % / 97.5 % of the pixels within 1e-4, worst 4.0e-4 / 7.4e-4, PSNR 92.1 / 86.1 dB
+    assert_mostly_close(lego["rgb"][ys, xs].cpu().numpy(), want["rgb_map"], what="rgb", frac=0.95, hard=2e-3, psnr_min=82.0)
+    assert_mostly_close(lego["acc"][ys, xs].cpu().numpy(), want["acc_map"], what="acc", frac=0.95, hard=2e-3, psnr_min=78.0)
     mse = float(np.mean((lego["rgb"][ys, xs].cpu().numpy() - want["rgb_map"]) ** 2))
     assert -10 * np.log10(mse + 1e-30) > 50.0
 

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import nerf_fixtures as fx
-from conftest import assert_bit_exact, assert_mostly_close
+from conftest import assert_bit_exact, assert_mostly_close, E2E_BARS
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +83,8 @@ def test_render_rays_vs_reference(gold, nets, query_fn, name):
     np.testing.assert_allclose(host(disp), gold[f"rr_{name}_disp_map"], atol=1e-4, rtol=1e-4)
     # end to end
     for k in ("rgb_map", "acc_map", "disp_map", "z_std"):
-        assert_mostly_close(host(ret[k]), gold[f"rr_{name}_{k}"], what=k, rtol=1e-4 if k == "disp_map" else 0.0)
+        assert_mostly_close(host(ret[k]), gold[f"rr_{name}_{k}"], what=f"{name} {k}", rtol=1e-4 if k == "disp_map" else 0.0,
+                            **E2E_BARS[name])
 
 
 def test_render_rays_smooth_end_to_end(gold, query_fn):
@@ -116,8 +117,8 @@ def test_render_rays_noview_and_samefine(gold):
         np.testing.assert_allclose(host(ret["rgb_map"]), gold["rr_noview_rgb_map"], atol=1e-4, rtol=0)
         np.testing.assert_allclose(host(ret["raw"]), gold["rr_noview_raw"], atol=1e-4, rtol=1e-4)
         ret = render_rays(rays, small, q, 64, N_importance=32, network_fine=None, white_bkgd=False)
-    assert_mostly_close(host(ret["rgb_map"]), gold["rr_samefine_rgb_map"], what="rgb")
-    assert_mostly_close(host(ret["z_std"]), gold["rr_samefine_z_std"], what="z_std")
+    assert_mostly_close(host(ret["rgb_map"]), gold["rr_samefine_rgb_map"], what="rgb")      # measured: all within 4.2e-5
+    assert_mostly_close(host(ret["z_std"]), gold["rr_samefine_z_std"], what="z_std")         # 7.0e-5
 
 
 def test_render_from_pose(gold, nets, query_fn):
@@ -136,8 +137,9 @@ def test_render_from_pose(gold, nets, query_fn):
         rgb, disp, acc, extras = render(H, W, K, chunk=100, c2w=c2w, near=2., far=6., **kw)
     assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and acc.shape == (H, W)
     np.testing.assert_allclose(host(extras["rgb0"]), gold["render_blender_rgb0"], atol=1e-4, rtol=0)
-    assert_mostly_close(host(rgb), gold["render_blender_rgb"], what="rgb")
-    assert_mostly_close(host(acc), gold["render_blender_acc"], what="acc")
+    # measured: 98.6 % / 97.9 % of the pixels within 1e-4, worst 2.2e-4 / 3.8e-4, PSNR 93.2 / 87.4 dB
+    assert_mostly_close(host(rgb), gold["render_blender_rgb"], what="rgb", frac=0.95, hard=1e-3, psnr_min=85.0)
+    assert_mostly_close(host(acc), gold["render_blender_acc"], what="acc", frac=0.95, hard=1e-3, psnr_min=80.0)
     # chunk size does not change the result (render.py:257-258)
     with torch.no_grad():
         rgb2, _, _, _ = render(H, W, K, chunk=1 << 15, c2w=c2w, near=2., far=6., **kw)
@@ -153,7 +155,7 @@ def test_render_from_pose(gold, nets, query_fn):
     kw.update(white_bkgd=False, ndc=True, N_importance=64)
     with torch.no_grad():
         rgb, disp, acc, _ = render(H, W, K, chunk=50, c2w=c2w, near=0., far=1., **kw)
-    assert_mostly_close(host(rgb), gold["render_ndc_rgb"], what="ndc rgb")
+    assert_mostly_close(host(rgb), gold["render_ndc_rgb"], what="ndc rgb", psnr_min=90.0)       # measured: all within 6.9e-5
     # static camera branch (render.py:286-288)
     H = W = 6
     K, _ = fx.intrinsics(H, W)
@@ -161,7 +163,8 @@ def test_render_from_pose(gold, nets, query_fn):
     with torch.no_grad():
         rgb, _, _, _ = render(H, W, K, chunk=1 << 15, c2w=dev(gold["render_blender_c2w"]), near=2., far=6.,
                               c2w_staticcam=dev(gold["render_static_c2w"]), **kw)
-    assert_mostly_close(host(rgb), gold["render_static_rgb"], what="staticcam rgb")
+    # measured: 97.2 % within 1e-4, worst 1.6e-4, PSNR 92.2 dB
+    assert_mostly_close(host(rgb), gold["render_static_rgb"], what="staticcam rgb", frac=0.94, hard=5e-4, psnr_min=85.0)
 
 
 def test_embedder_and_sample_pdf_surface(gold):
@@ -268,4 +271,4 @@ def test_fixed_random_route_vs_reference(query_fn, name, kw):
     # the fine net's raw outputs sit at resampled positions: a 1e-7 difference in a coarse weight moves a few of the
     # 128 random draws by a bin (the discontinuity discussed in conftest.assert_mostly_close); the rendered values
     # above are insensitive to it
-    assert_mostly_close(host(ret["raw"]), G[f"{name}_raw"], atol=1e-4, frac=0.99, hard=5e-2, what=f"{name} raw")
+    assert_mostly_close(host(ret["raw"]), G[f"{name}_raw"], atol=1e-4, frac=0.995, hard=5e-3, what=f"{name} raw")   # measured 99.8 % / 1.3e-3

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import nerf_fixtures as fx
-from conftest import assert_bit_exact, assert_mostly_close
+from conftest import assert_bit_exact, assert_mostly_close, E2E_BARS
 from oracle import oracle as orc
 
 
@@ -133,8 +133,8 @@ def test_render_rays(gold, name):
     np.testing.assert_allclose(disp, gold[f"rr_{name}_disp_map"], atol=1e-5, rtol=1e-5)
     # end to end (the oracle's own coarse weights drive the resampler): see assert_mostly_close
     for k in ("rgb_map", "acc_map", "disp_map", "z_std"):
-        assert_mostly_close(ret[k], gold[f"rr_{name}_{k}"], what=k, frac=0.9, hard=2e-2,
-                            rtol=1e-4 if k == "disp_map" else 0.0)
+        assert_mostly_close(ret[k], gold[f"rr_{name}_{k}"], what=f"{name} {k}", rtol=1e-4 if k == "disp_map" else 0.0,
+                            **E2E_BARS[name])
 
 
 def test_render_rays_smooth_end_to_end(gold):
@@ -169,8 +169,11 @@ def test_rays_and_render(gold):
     fine = orc.Net(fx.make_nerf_state(22, peaky=True))
     rays = orc.build_rays(H, W, K, c2w=gold["render_blender_c2w"], near=2., far=6.)
     ret = orc.render_rays(rays, coarse, fine, 64, 128, False, True)
-    assert_mostly_close(ret["rgb_map"].reshape(H, W, 3), gold["render_blender_rgb"], what="rgb")
-    assert_mostly_close(ret["acc_map"].reshape(H, W), gold["render_blender_acc"], what="acc")
+    # measured: 99.3 % within 1e-4, worst 2.2e-4 / 3.8e-4 (the HIP path shows the same worst pixels)
+    assert_mostly_close(ret["rgb_map"].reshape(H, W, 3), gold["render_blender_rgb"], what="rgb", frac=0.95, hard=1e-3,
+                        psnr_min=85.0)
+    assert_mostly_close(ret["acc_map"].reshape(H, W), gold["render_blender_acc"], what="acc", frac=0.95, hard=1e-3,
+                        psnr_min=80.0)
     np.testing.assert_allclose(ret["rgb0"].reshape(H, W, 3), gold["render_blender_rgb0"], atol=1e-5, rtol=0)
     # NDC
     H, W = 9, 12
@@ -282,5 +285,6 @@ def test_dnerf_render_rays(gold_dnerf, name):
     np.testing.assert_allclose(ret["rgb0"], g[f"rr_{name}_rgb0"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(dxs[0], g[f"rr_{name}_dx0"], atol=1e-5, rtol=0)
     for k in ("rgb_map", "acc_map"):
-        assert_mostly_close(ret[k], g[f"rr_{name}_{k}"], what=k)
-    assert_mostly_close(dxs[1], g[f"rr_{name}_dx"], atol=2e-4, frac=0.995, hard=1.0, what="dx")
+        # measured on the sharp dx_scale-3 fixture: >= 95.8 % of the rays within 1e-4, worst 1.2e-3, PSNR >= 75 dB
+        assert_mostly_close(ret[k], g[f"rr_{name}_{k}"], what=f"{name} {k}", frac=0.93, hard=3e-3, psnr_min=70.0)
+    assert_mostly_close(dxs[1], g[f"rr_{name}_dx"], atol=2e-4, frac=0.995, hard=5e-2, what="dx")   # 99.9 % / 1.0e-2
