@@ -130,6 +130,22 @@ def pmc_mfma_util(workload, kernel):
         return {}
 
 
+def multi_gpu_report(torch, dist, world, device, local_ms, events, key):
+    """What an N > 1 line says about itself: `world` as the process group sees it, each rank's kernel time per step (query
+    launches for the render workloads, the whole step for training) and the collective's time per step on rank 0 (HIP
+    events around the gather / all-reduce wait).  Collective call on every rank; {} at N = 1."""
+    if world == 1:
+        return {}
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([local_ms], device=device if on_gpu else "cpu", dtype=torch.float64)
+    per = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(per, t)
+    ms = [a.elapsed_time(b) for a, b in events]
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(),
+            "per_rank_ms_per_step": [round(float(x.item()), 3) for x in per],
+            key: round(sum(ms) / max(len(ms), 1), 3) if ms else None}
+
+
 def hbm_kernels(torch, device, n_rays=32768, reps=20):
     """Achieved GB/s of the sampling / compositing kernels at the render chunk size: algorithmic bytes per launch
     (inputs read once + outputs written once) over the HIP-event duration, `reps` back-to-back launches."""
@@ -325,7 +341,9 @@ def main():
                 kw2 = {k: v for k, v in kw.items() if k not in ("ndc", "use_viewdirs")}
                 return parallel.render_rows(H, W, K, c2w, row0, nrows, chunk=32768, ndc=kw["ndc"], near=near, far=far,
                                             use_viewdirs=True, **kw2)
-            return parallel.render_sharded(rows, H, W, rank, world)
+            return parallel.render_sharded(rows, H, W, rank, world, timings=timings)
+
+    timings = {}
 
     def fence():
         if world > 1:
@@ -347,6 +365,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    mg = multi_gpu_report(torch, dist, world, device, timer.summary()[0] / max(args.steps, 1),
+                          timings.get("gather", [])[-args.steps:], "gather_ms")
     if rank == 0:
         n_rays = H * W
         q_ms, q_pts, q_n = timer.summary()
@@ -385,6 +405,7 @@ def main():
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": q_pts / max(q_n, 1),
                          "query_share_of_step": q_ms * 1e-3 / dt},
         }
+        out.update(mg)
         out["roofline"].update(pmc_mfma_util("render_bf16" if bf16 else ("render_bf16x3" if x3 else "render"),
                                              "query_fwd_bf16_kernel<8, true>" if bf16
                                              else ("query_fwd_bf16x3_kernel<8, true>" if x3

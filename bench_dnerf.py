@@ -38,7 +38,7 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
     H = W = args.size
     K, _ = fx.intrinsics(H, W)
 
-    events, enabled = [], [False]
+    events, enabled, timings = [], [False], {}
     orig = vd.DNeRF_Deformation.query_points
 
     def timed(self, pts, *a, **k):
@@ -56,15 +56,12 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
         c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
         tval = 0.1 + 0.8 * ((i * 7) % 10) / 10.0
         with torch.no_grad():
-            if world == 1:
+            if world == 1 and not getattr(args, "sharded_path", False):
                 return vd.render_dnerf(H, W, K, tval, chunk=32768, c2w=c2w, near=2., far=6., **kw)[0]
-            ro_full, rd_full = get_rays(H, W, K, c2w)
 
-            def rows(row0, nrows):
-                rays = torch.stack([ro_full[row0:row0 + nrows].reshape(-1, 3), rd_full[row0:row0 + nrows].reshape(-1, 3)])
-                rgb, disp, acc, _ = vd.render_dnerf(H, W, K, tval, chunk=32768, rays=rays, near=2., far=6., **kw)
-                return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
-            return parallel.render_sharded(rows, H, W, rank, world)
+            def rows(row0, nrows):       # a rank's share: (row range, pose, time, intrinsics) -- no ray data moves
+                return parallel.render_rows_dnerf(H, W, K, c2w, tval, row0, nrows, chunk=32768, near=2., far=6., **kw)
+            return parallel.render_sharded(rows, H, W, rank, world, timings=timings)
 
     def fence():
         if world > 1:
@@ -85,9 +82,12 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
         t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    q_ms = sum(a.elapsed_time(b) for a, b, _ in events)
+    from bench import multi_gpu_report
+    mg = multi_gpu_report(torch, dist, world, device, q_ms / max(args.steps, 1), timings.get("gather", [])[-args.steps:],
+                          "gather_ms")
     out = None
     if rank == 0:
-        q_ms = sum(a.elapsed_time(b) for a, b, _ in events)
         q_pts = sum(n for _, _, n in events)
         achieved = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12 if q_ms > 0 else 0.0
         out = {
@@ -107,6 +107,7 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
                          "launches": len(events), "avg_launch_ms": q_ms / max(len(events), 1),
                          "flop_per_point": FLOP_PER_POINT, "query_share_of_step": q_ms * 1e-3 / dt},
         }
+        out.update(mg)
         if emit:
             print(json.dumps(out), flush=True)
     if world > 1 and emit:

@@ -316,3 +316,25 @@ def test_render_path_dnerf(parts):
     with torch.no_grad():
         r2, _ = vd.render_path_dnerf(poses[:1], times[:1], [H, W, focal], K, 1 << 15, kw, render_factor=2)
     assert r2.shape == (1, H // 2, W // 2, 3)
+
+
+def test_render_dnerf_row_shards_equal_whole(parts):
+    """parallel.render_rows_dnerf: what rank r of an N-GPU render_dnerf computes from (rows, pose, time, intrinsics)
+    alone.  The concatenation of ragged row shards is bit-identical to the single-GPU image, for a scalar time and for
+    per-pixel times (each rank takes its rows of the time image)."""
+    from nerf_amd import parallel
+    vd, model, qfn, _, _ = parts
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=64, network_fine=None,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+    H, W = 13, 10
+    K, _ = fx.intrinsics(H, W)
+    c2w = dev(fx.pose_spherical(20.0, -30.0, 4.0)[:3, :4])
+    per_pixel = torch.linspace(0.05, 0.95, H * W, device="cuda")
+    for tv in (0.5, per_pixel):
+        with torch.no_grad():
+            rgb, disp, acc, _ = vd.render_dnerf(H, W, K, tv, chunk=37, c2w=c2w, near=2., far=6., **kw)
+            whole = torch.cat([rgb, disp[..., None], acc[..., None]], -1)
+            for world in (2, 3):
+                shards = [parallel.render_rows_dnerf(H, W, K, c2w, tv, r0, n, chunk=64, near=2., far=6., **kw)
+                          for r0, n in parallel.row_partition(H, world)]
+                assert torch.equal(torch.cat(shards, 0).reshape(H, W, 5), whole)

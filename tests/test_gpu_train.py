@@ -1,5 +1,7 @@
 """Training step on the GPU (train.py:226-243: render -> img2mse(rgb)+img2mse(rgb0) -> backward) against
 the gradients the reference's autograd produced (tests/golden/static.npz, `train_*`)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -112,3 +114,64 @@ def test_adam_step_and_repack(gold):
         losses.append(loss.item())
         assert all(torch.isfinite(p.grad).all() for p in coarse.parameters())
     assert len(set(losses)) == 3
+
+
+def test_bucketed_allreduce_streams_on_the_gpu():
+    """BucketedGradAllReduce's overlapped path (side stream + async RCCL all-reduce started from the gradient hooks) in a
+    one-rank nccl group on this GPU: a real training backward (render -> loss -> backward through both nets), launch
+    order fine -> coarse, gradients bit-identical to the same backward without the reducer (average over one rank).
+    Runs in a child process so that the test process never holds a process group."""
+    import subprocess
+    import sys
+    script = r"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+import nerf_fixtures as fx
+from nerf_amd import parallel
+from nerf_amd.network import NeRF
+from nerf_amd.positional_encoding import get_embedder
+from nerf_amd.render import render, run_network
+from nerf_amd.utils import img2mse
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(sys.argv[1]), rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+nets = []
+for seed in (21, 22):
+    n = NeRF(8, 256, 63, 27, 5, [4], True)
+    n.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_nerf_state(seed, peaky=True).items()})
+    nets.append(n.cuda())
+coarse, fine = nets
+e10, _ = get_embedder(10, 0); e4, _ = get_embedder(4, 0)
+kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
+          network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.,
+          ndc=False, lindisp=False)
+ro, rd, target = fx.train_batch(256, seed=5)
+rays = torch.stack([torch.from_numpy(ro), torch.from_numpy(rd)]).cuda()
+tgt = torch.from_numpy(target).cuda()
+K, _ = fx.intrinsics(400, 400)
+params = list(fine.parameters()) + list(coarse.parameters())
+def backward():
+    for p in params:
+        p.grad = None
+    rgb, _, _, ex = render(400, 400, K, chunk=32768, rays=rays, retraw=True, near=2., far=6., **kw)
+    (img2mse(rgb, tgt) + img2mse(ex["rgb0"], tgt)).backward()
+backward()
+want = [p.grad.clone() for p in params]
+ar = parallel.BucketedGradAllReduce([list(fine.parameters()), list(coarse.parameters())], min_world=1)
+for it in range(3):
+    backward()
+    order = ar.finish()
+    assert order == [0, 1], order
+    torch.cuda.synchronize()
+    for p, w in zip(params, want):
+        assert torch.equal(p.grad, w)
+dist.destroy_process_group()
+print("BUCKETED_OK")
+"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-c", script, str(port)], capture_output=True, text=True, timeout=110,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "BUCKETED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
