@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
     ap.add_argument("--train-rays", type=int, default=4096, help="global ray batch of the train workload")
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="train workload: fp32 = the reference's arithmetic; bf16x3 = three bf16 MFMAs per f32 product "
+                         "(f32-grade results, gradients within the same 2e-3 of the reference's autograd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-path", action="store_true", help="use the multi-GPU row-sharded code path even with one GPU")
     ap.add_argument("--graph", action="store_true",
@@ -232,6 +235,9 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
     a = copy.copy(args)
     a.steps, a.warmup = 10, 3
     also["train_step"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
+    a.train_precision = "bf16x3"
+    also["train_step_bf16x3"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
+    a.train_precision = "fp32"
     a.steps, a.warmup = 2, 1
     for prec in ("fp32", "bf16", "bf16x3"):
         a.precision = prec

@@ -36,6 +36,8 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
     from nerf_amd.utils import img2mse
 
     coarse, fine = build_nets(torch, device)
+    tprec = getattr(args, "train_precision", "fp32")
+    coarse.train_precision = fine.train_precision = tprec
     params = list(coarse.parameters()) + list(fine.parameters())
     from nerf_amd.optim import FusedAdam
     opt = FusedAdam(params, lr=5e-4, betas=(0.9, 0.999))   # what create_nerf hands out on the GPU
@@ -103,9 +105,9 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
             "value": n_global * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if tprec == "fp32" else tprec, "data": "synthetic",
             "config": {"workload": f"lego-shaped training step, {n_global}-ray batch, 64+128 samples, D=8 W=256 coarse+fine, "
-                                   "fp32, forward+backward+Adam", "global_batch_rays": n_global,
+                                   f"{tprec}, forward+backward+Adam", "global_batch_rays": n_global,
                        "parallelism": f"dp{world}, two gradient buckets (fine, coarse: 2.38 MB each), the first all-reduce "
                                       "overlapped with the coarse net's backward" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

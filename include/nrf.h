@@ -200,6 +200,14 @@ int nrf_mlp_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, vo
 int nrf_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
                          const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
 
+/* Training forward on the bf16x3 arithmetic (no counterpart in the reference): nrf_query_fwd_train with every product as
+ * three bf16 MFMAs on hi/residual operands.  `packed` is the bf16x3 stream of nrf_mlp_bf16x3_pack_weights; raw agrees with
+ * nrf_query_fwd_train's to ~1e-5 of its scale; `acts` is filled in the SAME f32 layout (nrf_train_acts_floats), so
+ * nrf_query_bwd / nrf_query_bwd_input / nrf_query_bwd_static take it as it is (with the f32 `packed` of nrf_mlp_pack_weights). */
+int nrf_query_fwd_train_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                               const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
+                               void *stream);
+
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */
 int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb);

@@ -511,6 +511,8 @@ struct Bf16Args {
     int64_t n_points;
     int32_t pts_per_ray, n_trunk, skip_in_mask, use_viewdirs, output_ch, dbg, pad_[2];
     unsigned long long *prof_out;
+    float *acts;             // bf16x3 training forward: [n_points / 32 tiles][tl.a_tile] f32 T8 workspace
+    TrainLayout tl;
 };
 
 
@@ -598,8 +600,24 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t 
     lo = pack2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
-template <int NT>
-__device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&acc)[NT], bool relu) {
+// Training mode (nrf_query_fwd_train_bf16x3): where a wave's 32-point tile saves what the backward pass needs, in the f32
+// T8 workspace layout of the exact-f32 training kernels (TrainLayout, mlp_layout.h) -- so nrf_query_bwd consumes it as it is.
+struct X3Save {
+    TBuf tb;          // this wave's tile of `acts` (zero records for a tile beyond the workspace: stores are dropped)
+    int lane;
+};
+
+// sec: T8 section (floats from the tile base) the f32 values are saved to; gate_slot >= 0: also the ReLU gate bits
+// (bit order of store_gate_bits).  The stores sit in the conversion phase, where the matrix pipe is idle anyway.
+template <int NT, bool TRAIN = false>
+__device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&acc)[NT], bool relu,
+                                             const X3Save *sv = nullptr, uint32_t sec = 0, int gate_slot = -1) {
+    uint32_t gm[4] = {0u, 0u, 0u, 0u};
+    int voff = 0;
+    if constexpr (TRAIN) {
+        voff = ((sv->tb.m * (32 * NT) + 4 * sv->tb.h) * 8 + sv->tb.q7) * 4;
+        asm volatile("" : "+s"(sec));
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         float r[16];
@@ -612,6 +630,16 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
 #pragma unroll
             for (int k = 0; k < 16; ++k) asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[k]) : "v"(r[k]));
         }
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), sv->tb.rsrc, voff,
+                                                      (int)((sec + (32 * t + 8 * (k >> 2) + (k & 3)) * 8) * 4), 0);
+            if (gate_slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) gm[t >> 1] = (gm[t >> 1] << 1) | min(__float_as_uint(r[k]), 1u);
+            }
+        }
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             uint32_t hi, lo;
@@ -621,14 +649,21 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (TRAIN) {
+        if (gate_slot >= 0) {
+            if constexpr (NT & 1) gm[NT >> 1] <<= 16;
+            u32x4 v = {gm[0], gm[1], gm[2], gm[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(v, sv->tb.rsrc, sv->lane * 16, gate_slot * 4, 0);
+        }
+    }
 }
 
 // gamma(v) of a 3-vector (slot order of bf_pe3_chan), every frequency by an accurate sincos (nrf_sincos): the recurrence of
 // fill_pe3_bf16 is only good to ~2^-16
 template <int KS>
-__device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], float x, float y, float z, int h) {
+__device__ __forceinline__ void fill_pe3_x3_v(u32x4v (&oh)[KS], u32x4v (&ol)[KS], float (&v)[8 * KS], float x, float y, float z,
+                                              int h) {
     constexpr int NF = (8 * KS - 2) / 6;
-    float v[8 * KS];
     v[0] = h ? z : x;
     v[1] = h ? 1.0f : y;
     const float co[3] = {x, y, z};
@@ -652,15 +687,41 @@ __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
             ol[k][w] = lo;
         }
 }
+template <int KS>
+__device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], float x, float y, float z, int h) {
+    float v[8 * KS];
+    fill_pe3_x3_v<KS>(oh, ol, v, x, y, z, h);
+}
+
+// Training mode: gamma(v) into the T8 input section in the exact-f32 kernels' k-step order (blk_chan BLK_PE3 with KS32
+// steps: steps 6j..6j+5 = sin(xyz), cos(xyz) of frequency 2j + h, step KS32-2 = x | y, step KS32-1 = z | pad), from the
+// slot-ordered values of fill_pe3_x3_v (slot 2 + 6j + r <-> step 6j + r: both lists give lane half h the frequencies 2j + h).
+// Frequencies >= L are stored as computed: the weight-gradient unpack drops those columns (blk_chan returns -1).
+template <int KS, int KS32>
+__device__ __forceinline__ void save_pe3_t8(const X3Save &sv, uint32_t sec, const float (&v)[8 * KS], float x, float y, float z) {
+    constexpr int NF = (8 * KS - 2) / 6;
+    static_assert(6 * NF <= KS32 - 2, "the f32 k-step list must hold every frequency pair");
+    const int h = sv.tb.h;
+    const int voff = ((sv.tb.m * (2 * KS32) + h) * 8 + sv.tb.q7) * 4;
+    asm volatile("" : "+s"(sec));
+#pragma unroll
+    for (int st = 0; st < KS32; ++st) {
+        float val = 0.0f;
+        if (st < 6 * NF) val = v[2 + st];
+        else if (st == KS32 - 2) val = h ? y : x;
+        else if (st == KS32 - 1) val = h ? 0.0f : z;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), sv.tb.rsrc, voff, (int)((sec + 2 * st * 8) * 4), 0);
+    }
+}
 
 // Trunk of one net in bf16x3: layer 0 on S0 encoded k-steps (B0h, B0l), then the hidden layers.
-template <int NT, int S0, class B0H, class B0L>
+template <int NT, int S0, bool TRAIN = false, class B0H, class B0L>
 __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
                                             const u32x4v (&xh)[kBfKsX], const u32x4v (&xl)[kBfKsX], const u32x4v &one,
                                             const u32x4v &none, WStreamX3 &st, int n_trunk, int skip_in_mask, B0H &&b0h,
-                                            B0L &&b0l) {
+                                            B0L &&b0l, const X3Save *sv = nullptr, uint32_t a_trunk = 0, int a_mask = 0) {
     gemm_layer_x3<NT, S0>(acc, st, b0h, b0l);
-    pack_acts_x3<NT>(hh, hl, acc, true);
+    pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk, a_mask);
     for (int l = 1; l < n_trunk; ++l) {
         if ((skip_in_mask >> l) & 1)
             gemm_layer_x3<NT, kBfKsX + 2 * NT>(
@@ -671,36 +732,37 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
             gemm_layer_x3<NT, 2 * NT + 1, true>(
                 acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                 [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });
-        pack_acts_x3<NT>(hh, hl, acc, true);
+        pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk + l * (32 * 32 * NT), a_mask + l * 256);
     }
 }
 
 // View-direction head in bf16x3 (network.py:56-65) -> (rgb, alpha) of the wave's point tile, stored by lane half 0.
-template <int NT>
+template <int NT, bool TRAIN = false>
 __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
                                                  const u32x4v (&dh)[kBfKsD], const u32x4v (&dl)[kBfKsD], const u32x4v &one,
                                                  const u32x4v &none, WStreamX3 &st, const float *hb, int64_t pp,
-                                                 int64_t n_points, int h, float *raw) {
+                                                 int64_t n_points, int h, float *raw, const X3Save *sv = nullptr,
+                                                 uint32_t a_feat = 0, uint32_t a_hv = 0, int hv_gate_slot = -1) {
     f32x16 acc1[1];
     gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });      // network.py:56
     const float alpha = acc1[0][0] + hb[kHbAlpha];
     gemm_layer_x3<NT, 2 * NT + 1, true>(acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                                   [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });   // network.py:57
-    pack_acts_x3<NT>(hh, hl, acc, false);
+    pack_acts_x3<NT, TRAIN>(hh, hl, acc, false, sv, a_feat, -1);
     f32x16 acc2[NT / 2];
     gemm_layer_x3<NT / 2, 2 * NT + kBfKsD>(                                                                          // network.py:58-62
         acc2, st,
         [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(dh[s >= 2 * NT ? s - 2 * NT : 0]); },
         [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(dl[s >= 2 * NT ? s - 2 * NT : 0]); });
     u32x4v vh[NT], vl[NT];
-    pack_acts_x3<NT / 2>(vh, vl, acc2, true);
+    pack_acts_x3<NT / 2, TRAIN>(vh, vl, acc2, true, sv, a_hv, hv_gate_slot);
     gemm_layer_x3<1, NT>(acc1, st, [&](int s) { return as_bf(vh[s]); }, [&](int s) { return as_bf(vl[s]); });         // network.py:64
     if (h == 0 && pp < n_points)
         reinterpret_cast<float4 *>(raw)[pp] = make_float4(acc1[0][0] + hb[kHbRgb], acc1[0][1] + hb[kHbRgb + 1],
                                                           acc1[0][2] + hb[kHbRgb + 2], alpha);
 }
 
-template <int NT, bool VIEWS>
+template <int NT, bool VIEWS, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -722,20 +784,45 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
         const int64_t pc = pp < a.n_points ? pp : a.n_points - 1;
         u32x4v xh[kBfKsX], xl[kBfKsX];
         u32x4v dh[kBfKsD], dl[kBfKsD];
+        X3Save sv;
+        const X3Save *svp = nullptr;
+        if constexpr (TRAIN) {
+            // the workspace holds ceil(n_points / 32) tiles; a wave whose tile lies beyond it still runs (the weight
+            // stream is shared) with a zero-length descriptor, so its stores are dropped by the bounds check
+            const int64_t t32 = tile * 4 + st.wave;
+            const bool have = t32 < ((a.n_points + 31) >> 5);
+            sv.tb = make_tbuf(a.acts + (have ? t32 : 0) * a.tl.a_tile, have ? a.tl.a_tile : 0, lane);
+            sv.lane = lane;
+            svp = &sv;
+        }
         {
             const float *q = a.pts + pc * 3;
             if constexpr (VIEWS) {
                 const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
-                fill_pe3_x3<kBfKsD>(dh, dl, d[0], d[1], d[2], h);
+                if constexpr (TRAIN) {
+                    float v[8 * kBfKsD];
+                    fill_pe3_x3_v<kBfKsD>(dh, dl, v, d[0], d[1], d[2], h);
+                    save_pe3_t8<kBfKsD, kKsD>(sv, (uint32_t)a.tl.a_din, v, d[0], d[1], d[2]);
+                } else {
+                    fill_pe3_x3<kBfKsD>(dh, dl, d[0], d[1], d[2], h);
+                }
             }
-            fill_pe3_x3<kBfKsX>(xh, xl, q[0], q[1], q[2], h);
+            if constexpr (TRAIN) {
+                float v[8 * kBfKsX];
+                fill_pe3_x3_v<kBfKsX>(xh, xl, v, q[0], q[1], q[2], h);
+                save_pe3_t8<kBfKsX, kKsX>(sv, (uint32_t)a.tl.a_xin, v, q[0], q[1], q[2]);
+            } else {
+                fill_pe3_x3<kBfKsX>(xh, xl, q[0], q[1], q[2], h);
+            }
         }
         f32x16 acc[NT];
         u32x4v hh[2 * NT], hl[2 * NT];
-        bf_trunk_x3<NT, kBfKsX>(acc, hh, hl, xh, xl, one, none, st, a.n_trunk, a.skip_in_mask,
-                                [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); });   // network.py:48-53
+        bf_trunk_x3<NT, kBfKsX, TRAIN>(acc, hh, hl, xh, xl, one, none, st, a.n_trunk, a.skip_in_mask,
+                                       [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); },   // network.py:48-53
+                                       svp, (uint32_t)a.tl.a_trunk, (int)a.tl.a_mask);
         if constexpr (VIEWS) {
-            bf_views_head_x3<NT>(acc, hh, hl, dh, dl, one, none, st, hb, pp, a.n_points, h, a.raw);
+            bf_views_head_x3<NT, TRAIN>(acc, hh, hl, dh, dl, one, none, st, hb, pp, a.n_points, h, a.raw, svp,
+                                        (uint32_t)a.tl.a_feat, (uint32_t)a.tl.a_hv, (int)a.tl.a_mask + a.n_trunk * 256);
         } else {
             f32x16 acc1[1];
             gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:67
@@ -1129,18 +1216,19 @@ extern "C" int nrf_mlp_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed
     return bf_pack(P, packed, as_stream(stream));
 }
 
-extern "C" int nrf_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
-                                    const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
-    NRF_REQUIRE(net && emb, "nrf_query_fwd_bf16x3: null descriptor");
-    if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd_bf16x3: null pointer");
-    NRF_REQUIRE(n_points >= 0, "nrf_query_fwd_bf16x3: negative n_points");
-    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd_bf16x3: %s", e);
+static int query_fwd_x3_impl(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                             const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
+                             void *stream, const char *who) {
+    NRF_REQUIRE(net && emb, "%s: null descriptor", who);
+    if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "%s: null pointer", who);
+    NRF_REQUIRE(n_points >= 0, "%s: negative n_points", who);
+    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e);
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
-                "nrf_query_fwd_bf16x3: packed and raw must be 16-byte aligned");
+                "%s: packed and raw must be 16-byte aligned", who);
     if (net->use_viewdirs && n_points != 0) {
-        NRF_REQUIRE(viewdirs, "nrf_query_fwd_bf16x3: viewdirs is null but the net uses view directions");
+        NRF_REQUIRE(viewdirs, "%s: viewdirs is null but the net uses view directions", who);
         NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0,
-                    "nrf_query_fwd_bf16x3: n_points (%lld) must be a multiple of pts_per_ray (%d)", (long long)n_points, pts_per_ray);
+                    "%s: n_points (%lld) must be a multiple of pts_per_ray (%d)", who, (long long)n_points, pts_per_ray);
     }
     if (n_points == 0) return NRF_OK;
     BfPlan P;
@@ -1154,20 +1242,35 @@ extern "C" int nrf_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb
     a.skip_in_mask = 0;
     for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
     a.use_viewdirs = net->use_viewdirs; a.output_ch = net->output_ch;
+    a.acts = acts;
+    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
     const int64_t ntiles = (n_points + 127) / 128;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);
     hipStream_t st = as_stream(stream);
-    switch (net->W / 32) {
-        case 8:
-            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a);
-            break;
-        case 4:
-            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a);
-            break;
+    switch (net->W / 32 + (net->use_viewdirs ? 0 : 100) + (acts ? 1000 : 0)) {
+        case 8: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 108: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 104: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1008: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1108: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1004: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1104: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false, true>), dim3(blocks), dim3(256), 0, st, a); break;
     }
-    return check_launch("nrf_query_fwd_bf16x3");
+    return check_launch(who);
+}
+
+extern "C" int nrf_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                    const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
+    return query_fwd_x3_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, nullptr, stream, "nrf_query_fwd_bf16x3");
+}
+
+extern "C" int nrf_query_fwd_train_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                          const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw,
+                                          float *acts, void *stream) {
+    NRF_REQUIRE(acts || n_points == 0, "nrf_query_fwd_train_bf16x3: acts workspace is null");
+    return query_fwd_x3_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream,
+                             "nrf_query_fwd_train_bf16x3");
 }
 
 #ifdef NRF_BF16_PROFILE

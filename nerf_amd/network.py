@@ -27,7 +27,13 @@ class _QueryFunction(torch.autograd.Function):
         # need_grad is decided by the caller: inside forward grad mode is always off, and
         # ctx.needs_input_grad ignores torch.no_grad()
         if need_grad:
-            raw, acts = packed.query_train(pts, viewdirs, pts_per_ray)
+            packed.refresh()                     # the backward reads this f32 copy (W^T blocks of the dgrad chain)
+            fwd = packed
+            if module.train_precision == "bf16x3" and key[0] == 0 and module.W in (128, 256):
+                fwd = module._packed(key + ("bf16x3",))      # the forward alone runs on the bf16 matrix pipe
+            elif module.train_precision not in ("fp32", "bf16x3"):
+                raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', not {module.train_precision!r}")
+            raw, acts = fwd.query_train(pts, viewdirs, pts_per_ray)
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
             ctx.versions = packed._versions     # the dgrad chain reads the packed copy: it must still be this one
             ctx.save_for_backward(acts)
@@ -73,6 +79,9 @@ class NeRF(nn.Module):
         # two bf16 modes serve inference through render()'s fused query only.  Not part of the reference's constructor:
         # set as an attribute.
         self.precision = "fp32"
+        # arithmetic of queries that need gradients: "fp32" = exact f32 MFMA (the reference's arithmetic); "bf16x3" = the
+        # training forward as three bf16 MFMAs per product (f32-grade: raw within 1e-5 of its scale), backward in f32
+        self.train_precision = "fp32"
 
     # ------------------------------------------------------------------ packed weights
     def _packed(self, key):

@@ -457,3 +457,19 @@ class PackedNetBf16x3(PackedNetBf16):
                                               _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _stream()),
               "nrf_query_fwd_bf16x3")
         return raw
+
+    def query_train(self, pts, viewdirs=None, pts_per_ray=1):
+        """Training forward on the bf16x3 arithmetic -> (raw, acts); `acts` has the f32 kernels' layout, so the
+        backward entry points of the f32 PackedNet of the same module consume it."""
+        self.refresh()
+        pts = _f32(pts, "pts")
+        P = pts.shape[0]
+        raw = torch.empty((P, self.out_ch), device=pts.device, dtype=torch.float32)
+        n = _lib.lib().nrf_train_acts_floats(C.byref(self.net), P)
+        acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
+        if viewdirs is not None:
+            viewdirs = _f32(viewdirs, "viewdirs")
+        check(_lib.lib().nrf_query_fwd_train_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                                    _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _ptr(acts), _stream()),
+              "nrf_query_fwd_train_bf16x3")
+        return raw, acts
