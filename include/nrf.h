@@ -208,6 +208,14 @@ int nrf_query_fwd_train_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, con
                                const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
                                void *stream);
 
+/* Backward on the bf16x3 arithmetic (no counterpart in the reference): nrf_query_bwd (pts == g_pts == NULL) or
+ * nrf_query_bwd_input with the weight-gradient GEMMs dW = sum_points g x^T as three bf16 MFMAs per product on hi/residual
+ * operands split as they leave LDS; same arguments, workspaces (f32 layout) and result layout.  The activation-gradient chain
+ * runs on the exact f32 kernel.  Gradients agree with nrf_query_bwd's to ~1e-5 of their scale. */
+int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                         const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                         const float *pts, float *g_pts, void *stream);
+
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */
 int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb);

@@ -343,6 +343,96 @@ __device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[4][4], float (&bs)[4],
     }
 }
 
+// ---- bf16x3 wgrad: the same super-blocks, pieces, LDS ring and slabs; the contraction over points runs on
+// v_mfma_f32_32x32x16_bf16 with every f32 operand split into hi = bf16(v), lo = bf16(v - hi) as it leaves LDS:
+//   dW += Gh Xh^T + Gh Xl^T + Gl Xh^T      (the dropped Gl Xl^T is 2^-18 relative)
+// One MFMA covers the step's 16 points: lane (channel c, half s) supplies the 8 points of group s -- two 16-byte LDS reads
+// (the piece of group s holds points 0-3 of every channel in its first 512 bytes, points 4-7 in the second).  At three
+// MFMAs of 32 cycles per tile pair a full super-block asks for ~21 B/clk/CU of operands, twice what HBM delivers to 256
+// CUs: this kernel is HBM-bound (64 FLOP/B), the matrix pipe waits, and the conversion VALU work fills the gaps.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+struct WgFrag { u32x4 hi, lo; };
+
+__device__ __forceinline__ void wg_split(const f32x4 &p0, const f32x4 &p1, WgFrag &f) {
+    const float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((wg_f32x2){v[2 * w], v[2 * w + 1]}, wg_bf16x2));
+        const float ra = v[2 * w] - __uint_as_float(hi << 16), rb = v[2 * w + 1] - __uint_as_float(hi & 0xffff0000u);
+        f.hi[w] = hi;
+        f.lo[w] = __builtin_bit_cast(uint32_t, __builtin_convertvector((wg_f32x2){ra, rb}, wg_bf16x2));
+    }
+}
+
+template <int NA, int KA, class Req>
+__device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
+                                               int64_t nsteps, Req &&request) {
+    static_assert(kWgM == 2, "the bf16x3 step covers one 32x32x16 MFMA: two 8-point groups");
+    constexpr int NAr = NA ? NA : 1, KAr = KA ? KA : 1;
+    WgFrag A0[NAr], B0[KAr], A1[NAr], B1[KAr];
+    float R0[NAr], R1[NAr];                      // row sums of the G fragments (bias gradients)
+    auto read_frags = [&](WgFrag (&A)[NAr], WgFrag (&B)[KAr], float (&R)[NAr], int stage) {
+        const char *base = lds + stage * kWgStage + (lane >> 5) * 16384 + (lane & 31) * 16;
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(base + (nt0 + x) * 1024);
+            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(base + (nt0 + x) * 1024 + 512);
+            R[x] = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+            wg_split(p0, p1, A[x]);
+        }
+#pragma unroll
+        for (int y = 0; y < KA; ++y) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
+            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024 + 512);
+            wg_split(p0, p1, B[y]);
+        }
+    };
+    auto land = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int st_nxt = 1, st_req = 2;
+    auto body = [&](int64_t step, WgFrag (&A)[NAr], WgFrag (&B)[KAr], float (&R)[NAr], WgFrag (&An)[NAr], WgFrag (&Bn)[KAr],
+                    float (&Rn)[NAr]) {
+        land();
+        if (step + 2 < nsteps) request(step + 2, st_req);
+        if constexpr (NA > 0 && KA > 0) {
+            // the next step's fragments are read and split while this step's MFMAs run (the scheduler is free to interleave:
+            // the matrix pipe has slack here); past the last step this re-reads a stale stage: unused
+            read_frags(An, Bn, Rn, st_nxt);
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+                bs[x] += R[x];
+#pragma unroll
+                for (int y = 0; y < KA; ++y) {
+                    const wg_bf16x8 ah = __builtin_bit_cast(wg_bf16x8, A[x].hi), al = __builtin_bit_cast(wg_bf16x8, A[x].lo);
+                    const wg_bf16x8 bh = __builtin_bit_cast(wg_bf16x8, B[y].hi), bl = __builtin_bit_cast(wg_bf16x8, B[y].lo);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[x][y], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
+        st_req = st_req == 2 ? 0 : st_req + 1;
+    };
+    if (nsteps > 0) {
+        request(0, 0);
+        request(1, 1);          // nsteps is even
+        land();
+        if constexpr (NA > 0 && KA > 0) read_frags(A0, B0, R0, 0);
+    }
+    for (int64_t step = 0; step < nsteps; step += 2) {
+        body(step, A0, B0, R0, A1, B1, R1);
+        body(step + 1, A1, B1, R1, A0, B0, R0);
+    }
+}
+
+template <bool X3>
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
     const int lane = threadIdx.x & 63;
@@ -415,7 +505,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
     // exact wait counts); waves of one workgroup may run different instances, all with the same barrier sequence.
     auto run = [&](auto na_c, auto ka_c) {
         constexpr int NA = decltype(na_c)::value, KA = decltype(ka_c)::value;
-        wgrad_steps<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        if constexpr (X3) wgrad_steps_x3<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        else wgrad_steps<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
     };
     auto pick_k = [&](auto na_c) {
         switch (ka) {
@@ -538,6 +629,7 @@ struct Bwd {
     int nchunks, chunk_tiles;
     hipStream_t st;
     int64_t slab_off = 0, slab_cap = 0;    // floats: every GEMM gets its own region of `slab`
+    bool x3 = false;                       // wgrad on the bf16 matrix pipe (three bf16 MFMAs per product)
     ReduceBatch batch;
     int nbatch = 0, max_blocks = 1;
 
@@ -564,7 +656,8 @@ struct Bwd {
         const int sblks = ((n_tiles + 7) / 8) * ((w.k_tiles + 7) / 8);
         slab_off += (int64_t)nchunks * ((int64_t)n_tiles * 32 * w.k_tiles * 32 + n_tiles * 32);
         if (slab_off > slab_cap) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: slab workspace too small (internal)");
-        hipLaunchKernelGGL(wgrad_kernel, dim3(nchunks, sblks), dim3(256), 0, st, w);
+        if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunks, sblks), dim3(256), 0, st, w);
+        else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunks, sblks), dim3(256), 0, st, w);
         for (int i = 0; i < ndst; ++i) {
             int kc = 0;
             for (int q = 0; q < nparts; ++q) {
@@ -618,7 +711,8 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
 // return d(loss)/d(pts) (canonical nets with the fused encoding).
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
-                          const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256) {
+                          const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256,
+                          bool x3 = false) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
@@ -661,7 +755,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
 
     Bwd B{};
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
-    B.ntiles = ntiles; B.st = st;
+    B.ntiles = ntiles; B.st = st; B.x3 = x3;
     B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, max_chunks);
     B.slab_cap = slab_floats(net, n_points, max_chunks);
     const TrainLayout &tl = d.tl;
@@ -723,6 +817,13 @@ extern "C" int nrf_query_bwd_input(const nrf_net_t *net, const nrf_embed_t *emb,
                                    const float *pts, float *g_pts, void *stream) {
     NRF_REQUIRE(pts && g_pts, "nrf_query_bwd_input: pts / g_pts is null");
     return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream);
+}
+
+extern "C" int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                                    const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                                    const float *pts, float *g_pts, void *stream) {
+    NRF_REQUIRE((pts == nullptr) == (g_pts == nullptr), "nrf_query_bwd_bf16x3: pts and g_pts go together");
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream, 256, true);
 }
 
 extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,

@@ -36,6 +36,7 @@ class _QueryFunction(torch.autograd.Function):
             raw, acts = fwd.query_train(pts, viewdirs, pts_per_ray)
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
             ctx.versions = packed._versions     # the dgrad chain reads the packed copy: it must still be this one
+            ctx.x3 = fwd is not packed
             ctx.save_for_backward(acts)
             return raw
         return packed.query(pts, viewdirs, pts_per_ray)
@@ -49,7 +50,7 @@ class _QueryFunction(torch.autograd.Function):
             raise RuntimeError("nerf_amd: a parameter of this network was modified (optimizer.step(), load_state_dict) "
                                "between the forward and this backward; the packed weights no longer match the saved "
                                "activations")
-        grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts)
+        grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, x3=ctx.x3)
         order = [name for name, _ in ctx.module.named_parameters()]
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in order)
 
@@ -80,7 +81,8 @@ class NeRF(nn.Module):
         # set as an attribute.
         self.precision = "fp32"
         # arithmetic of queries that need gradients: "fp32" = exact f32 MFMA (the reference's arithmetic); "bf16x3" = the
-        # training forward as three bf16 MFMAs per product (f32-grade: raw within 1e-5 of its scale), backward in f32
+        # training forward and weight-gradient GEMMs as three bf16 MFMAs per product on hi/residual operands (f32-grade:
+        # raw within 1e-5 of its scale, gradients within the same 2e-3 of the reference's autograd)
         self.train_precision = "fp32"
 
     # ------------------------------------------------------------------ packed weights

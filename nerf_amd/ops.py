@@ -280,9 +280,9 @@ class PackedNet:
               "nrf_query_fwd_train")
         return raw, acts
 
-    def query_bwd(self, g_raw, n_points, acts, pts=None):
+    def query_bwd(self, g_raw, n_points, acts, pts=None, x3=False):
         """-> dict name -> gradient tensor (same shapes as the parameters); with `pts` (the query points of the
-        forward) -> (that dict, d(loss)/d(pts) [P,3])."""
+        forward) -> (that dict, d(loss)/d(pts) [P,3]).  x3: the weight-gradient GEMMs on the bf16x3 arithmetic."""
         g_raw = _f32(g_raw, "g_raw")
         dev = g_raw.device
         lib = _lib.lib()
@@ -301,6 +301,17 @@ class PackedNet:
             gn.rgb_w, gn.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
         else:
             gn.out_w, gn.out_b = g("output_linear.weight"), g("output_linear.bias")
+        if x3:
+            if self._bwd_fn() is not lib.nrf_query_bwd:
+                raise NotImplementedError("the bf16x3 backward is built for NeRF-shaped nets, not the deformation net")
+            g_pts = None
+            if pts is not None:
+                pts = _f32(pts, "pts")
+                g_pts = torch.empty((n_points, 3), device=dev, dtype=torch.float32)
+            check(lib.nrf_query_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw), _ptr(acts),
+                                           _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _ptr(pts), _ptr(g_pts),
+                                           _stream()), "nrf_query_bwd_bf16x3")
+            return grads if pts is None else (grads, g_pts)
         if pts is not None:
             pts = _f32(pts, "pts")
             g_pts = torch.empty((n_points, 3), device=dev, dtype=torch.float32)
