@@ -209,12 +209,16 @@ int nrf_query_fwd_train_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, con
                                void *stream);
 
 /* Backward on the bf16x3 arithmetic (no counterpart in the reference): nrf_query_bwd (pts == g_pts == NULL) or
- * nrf_query_bwd_input with the weight-gradient GEMMs dW = sum_points g x^T as three bf16 MFMAs per product on hi/residual
- * operands split as they leave LDS; same arguments, workspaces (f32 layout) and result layout.  The activation-gradient chain
- * runs on the exact f32 kernel.  Gradients agree with nrf_query_bwd's to ~1e-5 of their scale. */
-int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
-                         const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
-                         const float *pts, float *g_pts, void *stream);
+ * nrf_query_bwd_input with every GEMM as three bf16 MFMAs per product on hi/residual operands; same workspaces (f32
+ * layout) and result layout.  Weight-gradient GEMMs: operands split as they leave LDS.  Activation-gradient chain: W^T
+ * blocks streamed from `packed_bwd_x3` (nrf_mlp_bf16x3_bwd_pack_weights; NULL, input gradients requested, or a shape
+ * without a bf16x3 kernel: that chain runs on the exact f32 kernel instead).  `packed` is the f32 copy of
+ * nrf_mlp_pack_weights (head vectors; the f32 chain).  Gradients agree with nrf_query_bwd's to ~1e-5 of their scale. */
+int64_t nrf_mlp_bf16x3_bwd_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_mlp_bf16x3_bwd_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
+int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const void *packed_bwd_x3,
+                         const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
+                         const nrf_net_t *grads, const float *pts, float *g_pts, void *stream);
 
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */

@@ -58,8 +58,10 @@ _SIGS = {
     "nrf_query_fwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),
     "nrf_query_fwd_train_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp,
                                              vp, vp]),
-    "nrf_query_bwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
+    "nrf_query_bwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, vp, C.c_int64,
                                        C.POINTER(NrfNet), vp, vp, vp]),
+    "nrf_mlp_bf16x3_bwd_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
+    "nrf_mlp_bf16x3_bwd_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_mlp_bf16x3_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_mlp_bf16x3_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_dnerf_bf16_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),

@@ -69,6 +69,8 @@ struct BfLayer {
     int32_t ld, n_out, nt_out, nblk;
     int32_t tail;    // the last `tail` k-steps are stored tile-outer ([out tile][k-step]), the rest [k-step][out tile]
     int32_t split;   // bf16x3: every fragment is followed by its residual fragment, lo = bf16(w - float(bf16(w)))
+    int32_t transposed;   // backward chain: rows = W's INPUT channels col0 + out (n_out valid), contraction over W's output
+                          // channels (blk.ncols of them): the fragment holds W^T
     BfBlock blk[3];
     int64_t dst;   // byte offset in the stream
 };
@@ -100,7 +102,8 @@ __global__ void pack_bf16_kernel(BfLayer a, char *stream) {
             }
             float w = 0.0f;
             if (out < a.n_out) {
-                if (ch >= 0 && ch < B.ncols) w = a.W[(int64_t)out * a.ld + B.col0 + ch];
+                if (a.transposed) { if (ch >= 0 && ch < B.ncols) w = a.W[(int64_t)ch * a.ld + B.col0 + out]; }
+                else if (ch >= 0 && ch < B.ncols) w = a.W[(int64_t)out * a.ld + B.col0 + ch];
                 else if (ch == -2) w = a.b[out];
             }
             const __bf16 hi = (__bf16)w;
@@ -123,12 +126,17 @@ struct BfPlan {
     int64_t bytes = 0;
     void add(const float *W, const float *b, int ld, int n_out, int nt_out, int tail, BfBlock b0, BfBlock b1 = {}, BfBlock b2 = {}) {
         BfLayer &L = layer[n++];
-        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out; L.tail = tail; L.split = split;
+        L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out; L.tail = tail; L.split = split; L.transposed = 0;
         L.blk[0] = b0; L.blk[1] = b1; L.blk[2] = b2;
         L.nblk = 1 + (b1.type != BFB_NONE) + (b2.type != BFB_NONE);
         L.dst = bytes;
         int64_t ks = b0.ksteps + b1.ksteps + b2.ksteps;
         bytes += (ks * nt_out * (split ? 2 : 1) * kFrag + kChunk - 1) / kChunk * kChunk;
+    }
+    // W^T of the columns col0 .. col0 + k_valid of an nn.Linear with n_src outputs, as a layer of nt_out output tiles
+    void add_T(const float *W, int ld, int col0, int k_valid, int nt_out, int n_src) {
+        add(W, W, ld, k_valid, nt_out, 0, BfBlock{BFB_HIDDEN, 0, n_src / 16, col0, n_src});
+        layer[n - 1].transposed = 1;
     }
     void add_bias(const float *src, int n_, int dst) { bias[nbias++] = BfBiasEntry{src, n_, dst}; }
 };
@@ -192,6 +200,20 @@ static void bf_plan_net(BfPlan &P, const nrf_net_t *net, const nrf_embed_t *emb,
           BfBlock{BFB_PE3, emb->multires_views, kBfKsD, W, net->input_ch_views});   // network.py:58-62 (bias: CONST slot)
     P.add(net->rgb_w, net->rgb_b, W / 2, 3, 1, 0, BfBlock{BFB_HIDDEN, 0, nt, 0, W / 2});   // network.py:64
     P.add_bias(net->rgb_b, 3, kHbRgb);
+}
+
+// The activation-gradient chain's stream (nrf_query_bwd_bf16x3): W^T blocks in the order dgrad_x3_kernel consumes them --
+// views_linears[0][:, :W]^T, feature_linear^T, then the hidden parts of the trunk layers D-1 .. 1.
+static void bf_plan_net_bwd(BfPlan &P, const nrf_net_t *net) {
+    const int W = net->W, nt = W / 32, ic = net->input_ch, D = net->D;
+    if (net->use_viewdirs) {
+        P.add_T(net->views_w, W + net->input_ch_views, 0, W, nt, W / 2);
+        P.add_T(net->feature_w, W, 0, W, nt, W);
+    }
+    for (int l = D - 1; l >= 1; --l) {
+        const bool skip = (net->skips_mask >> (l - 1)) & 1;
+        P.add_T(net->pts_w[l], W + (skip ? ic : 0), skip ? ic : 0, W, nt, W);
+    }
 }
 
 __global__ void pack_bias_kernel(BfBiasEntry e, float *table) {
@@ -837,6 +859,150 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
     __builtin_amdgcn_s_barrier();
 }
 
+// ---- bf16x3 activation-gradient chain (the dgrad_kernel of mlp_bwd.hip on the bf16 matrix pipe) ------------------------
+// A gradient block on its way from one GEMM of the chain to the next: accumulators (or VGPR values) [+ sc * head vector]
+// -> ReLU gate -> saved in f32 to its T8 section of `gbuf` (what the weight-gradient GEMMs read) -> hi/residual operands.
+template <int NT, bool FROM_ACC, bool GATE, bool AXPY>
+__device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&src)[NT],
+                                               const u32x4 &gate, const WBuf &wb, uint32_t vec, float sc, const TBuf &tg,
+                                               uint32_t sec, int C) {
+    const int voff = ((tg.m * C + 4 * tg.h) * 8 + tg.q7) * 4;
+    asm volatile("" : "+s"(sec), "+s"(vec));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float r[16];
+        f32x4 hv[4];
+        if constexpr (AXPY) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) hv[gq] = wload(wb, wb.h16, (vec + ((t * 4 + gq) * 2) * 4) * 4);
+        }
+        if constexpr (FROM_ACC) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r[k]) : "a"(src[t][k]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r[k] = src[t][k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AXPY) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r[k] = fmaf(hv[k >> 2][k & 3], sc, r[k]);
+        }
+        if constexpr (GATE) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int mask = __builtin_amdgcn_sbfe((int)gate[t >> 1], 31 - (16 * (t & 1) + k), 1);
+                r[k] = __uint_as_float(__float_as_uint(r[k]) & (uint32_t)mask);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), tg.rsrc, voff,
+                                                  (int)((sec + (32 * t + 8 * (k >> 2) + (k & 3)) * 8) * 4), 0);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t hi, lo;
+            split2(r[2 * w], r[2 * w + 1], hi, lo);
+            hh[2 * t + (w >> 2)][w & 3] = hi;
+            hl[2 * t + (w >> 2)][w & 3] = lo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct DgradX3Args {
+    NetPlan plan;            // head-vector offsets into the f32 packed buffer
+    TrainLayout tl;
+    const float *packed;     // nrf_mlp_pack_weights
+    const char *stream;      // nrf_mlp_bf16x3_bwd_pack_weights
+    int64_t stream_bytes;
+    const float *g_raw, *acts;
+    float *gbuf;
+    int64_t n_points;
+};
+
+// Autograd of network.py:46-69 w.r.t. every layer's pre-activations, written to `gbuf` exactly as dgrad_kernel writes it.
+// Four waves share the W^T stream through LDS (the machinery of the query kernels); a wave owns one 32-point tile.
+template <int NT, bool VIEWS>
+__global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
+    const NetPlan &pl = a.plan;
+    const TrainLayout &tl = a.tl;
+    const int lane = threadIdx.x & 63, n = lane & 31;
+    constexpr int W = 32 * NT;
+    WStreamX3 st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
+    st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.start();
+    WBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.packed), 0, (int)(pl.total_floats * 4), 0x00020000);
+    wb.lane16 = lane * 16;
+    wb.h16 = (lane >> 5) * 16;
+    const int64_t ntiles = (a.n_points + 127) >> 7, n32 = (a.n_points + 31) >> 5;
+    const u32x4 nogate = {0u, 0u, 0u, 0u};
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // a wave whose 32-point tile lies beyond the workspaces still walks the stream (it is shared); zero-length
+        // descriptors drop its stores and return zeros for its loads
+        const int64_t t32 = tile * 4 + st.wave;
+        const bool have = t32 < n32;
+        const int64_t p = t32 * 32 + n;
+        const bool live = have && p < a.n_points;
+        TBuf ta = make_tbuf(const_cast<float *>(a.acts) + (have ? t32 : 0) * tl.a_tile, have ? tl.a_tile : 0, lane);
+        TBuf tg = make_tbuf(a.gbuf + (have ? t32 : 0) * tl.g_tile, have ? tl.g_tile : 0, lane);
+        f32x16 acc[NT];
+        u32x4v hh[2 * NT], hl[2 * NT];
+        u32x4 gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (pl.n_trunk - 1) * 256, lane);
+        if constexpr (VIEWS) {
+            const float4 gr = live ? reinterpret_cast<const float4 *>(a.g_raw)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float hv3[8] = {gr.x, gr.y, gr.z, 0.f, 0.f, 0.f, 0.f, 0.f};
+            store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, hv3, 3);            // d/d(rgb logits): rgb_linear's wgrad
+            {   // through rgb_linear (network.py:64) and the view layer's ReLU: three-term sums, on the VALU in f32
+                f32x16 g2[NT / 2];
+                zero_acc<NT / 2>(g2);
+                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 0 * (NT / 2) * 32, gr.x);
+                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NT / 2) * 32, gr.y);
+                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NT / 2) * 32, gr.z);
+                const u32x4 hvgate = load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane);
+                u32x4v vh[NT], vl[NT];
+                finish_grad_x3<NT / 2, false, true, false>(vh, vl, g2, hvgate, wb, 0u, 0.f, tg, (uint32_t)tl.g_hv, W / 2);
+                // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
+                gemm_layer_x3<NT, NT>(acc, st, [&](int s) { return as_bf(vh[s]); }, [&](int s) { return as_bf(vl[s]); });
+            }
+            finish_grad_x3<NT, true, false, false>(hh, hl, acc, nogate, wb, 0u, 0.f, tg, (uint32_t)tl.g_feat, W + 32);
+            const float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);          // d/d(alpha): alpha_linear's wgrad
+            // through feature_linear and alpha_linear (network.py:56-57) -> d/d(h_{D-1}), then that layer's ReLU
+            gemm_layer_x3<NT, 2 * NT>(acc, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });
+            finish_grad_x3<NT, true, true, true>(hh, hl, acc, gate, wb, (uint32_t)pl.alpha_vec, gr.w, tg,
+                                                 (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (32 * W), W);
+        } else {
+            float ho[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) ho[o] = (live && o < pl.output_ch) ? a.g_raw[p * pl.output_ch + o] : 0.0f;
+            store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
+            f32x16 g[NT];
+            zero_acc<NT>(g);
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < pl.output_ch) axpy_head<NT>(g, wb, (uint32_t)pl.out_vec + o * NT * 32, ho[o]);
+            finish_grad_x3<NT, false, true, false>(hh, hl, g, gate, wb, 0u, 0.f, tg,
+                                                   (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (32 * W), W);
+        }
+        // trunk in reverse (network.py:49-53): g_{l-1} = gate_{l-1} . (W_l[:, hidden]^T g_l)
+        for (int l = pl.n_trunk - 1; l >= 1; --l) {
+            gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);       // in flight during the GEMM
+            gemm_layer_x3<NT, 2 * NT>(acc, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });
+            finish_grad_x3<NT, true, true, false>(hh, hl, acc, gate, wb, 0u, 0.f, tg, (uint32_t)tl.g_trunk + (l - 1) * (32 * W), W);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests in flight must land before the LDS is released
+    __builtin_amdgcn_s_barrier();
+}
+
 // gamma(t) of a scalar into KS k-step fragments (slot order of bf_pe1_chan)
 template <int KS>
 __device__ __forceinline__ void fill_pe1_bf16(u32x4v (&out)[KS], float t, int h) {
@@ -1272,6 +1438,53 @@ extern "C" int nrf_query_fwd_train_bf16x3(const nrf_net_t *net, const nrf_embed_
     return query_fwd_x3_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream,
                              "nrf_query_fwd_train_bf16x3");
 }
+
+extern "C" int64_t nrf_mlp_bf16x3_bwd_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+    if (!net || !emb) return -1;
+    if (const char *e = bf_check_net(net, emb, false)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16x3_bwd_packed_bytes: %s", e); return -1; }
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net_bwd(P, net);
+    return bf_total_bytes(P);
+}
+
+extern "C" int nrf_mlp_bf16x3_bwd_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    NRF_REQUIRE(net && emb && packed, "nrf_mlp_bf16x3_bwd_pack_weights: null pointer");
+    if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16x3_bwd_pack_weights: %s", e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nrf_mlp_bf16x3_bwd_pack_weights: packed must be 16-byte aligned");
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net_bwd(P, net);
+    return bf_pack(P, packed, as_stream(stream));
+}
+
+// Called by query_bwd_impl (mlp_bwd.hip) in place of the f32 dgrad launch.  NRF_ERR_UNSUPPORTED (with nothing launched)
+// when the shape has no bf16x3 kernel: the caller then runs the f32 chain.
+namespace nrf {
+int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
+                    const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
+                    hipStream_t st) {
+    if (bf_check_net(net, emb, false) || net->D < 2) return NRF_ERR_UNSUPPORTED;
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net_bwd(P, net);
+    DgradX3Args a{};
+    a.plan = plan;
+    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    a.packed = packed; a.stream = (const char *)packed_bwd_x3; a.stream_bytes = P.bytes;
+    a.g_raw = g_raw; a.acts = acts; a.gbuf = gbuf; a.n_points = n_points;
+    const int64_t ntiles = (n_points + 127) / 128;
+    const int blocks = (int)(ntiles < 256 ? ntiles : 256);
+    switch (net->W / 32 + (net->use_viewdirs ? 0 : 100)) {
+        case 8: hipLaunchKernelGGL((dgrad_x3_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 108: hipLaunchKernelGGL((dgrad_x3_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((dgrad_x3_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 104: hipLaunchKernelGGL((dgrad_x3_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a); break;
+        default: return NRF_ERR_UNSUPPORTED;
+    }
+    return check_launch("nrf_query_bwd_bf16x3 (dgrad)");
+}
+}  // namespace nrf
 
 #ifdef NRF_BF16_PROFILE
 extern "C" int nrf_bf16_profile_set(unsigned long long *device_counters) { nrf::g_prof_host_ptr = device_counters; return 0; }

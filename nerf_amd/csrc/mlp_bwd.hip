@@ -19,14 +19,6 @@
 
 namespace nrf {
 
-template <int NT>
-__device__ __forceinline__ void zero_acc(f32x16 (&a)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[t][r] = 0.0f;
-}
-
 // store / load accumulator-layout registers into a T8 section of C channels starting at channel c0
 template <int NT>
 __device__ __forceinline__ void store_acc_t8c(const TBuf &tb, uint32_t sec, int C, const f32x16 (&v)[NT]) {
@@ -54,20 +46,6 @@ __device__ __forceinline__ void store_acc_t8c_group(const TBuf &tb, uint32_t sec
     }
 }
 __device__ __forceinline__ int t8c_voff(const TBuf &tb, int C) { return ((tb.m * C + 4 * tb.h) * 8 + tb.q7) * 4; }
-
-// head tile: 32 channels starting at channel c0 of a section with C channels; channel c0+o = vals[o] (o < n), else 0
-__device__ __forceinline__ void store_head_tile(const TBuf &tb, uint32_t sec, int C, int c0, const float (&vals)[8],
-                                                int n) {
-    const int voff = ((tb.m * C + c0 + 16 * tb.h) * 8 + tb.q7) * 4;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float v = 0.0f;
-#pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (tb.h == 0 && j == o && o < n) v = vals[o];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), tb.rsrc, voff, (int)((sec + j * 8) * 4), 0);
-    }
-}
 
 // acc = act > 0 ? acc : 0, with act read back from the saved activations.  One 32-channel tile (16 loads)
 // is in flight ahead of the tile being gated.
@@ -98,29 +76,9 @@ __device__ __forceinline__ void relu_mask_t8(const TBuf &ta, uint32_t sec, f32x1
     }
 }
 
-// g[t][r] += vec[channel] * s   (head weight vectors in accumulator order), loads one tile ahead
-template <int NT>
-__device__ __forceinline__ void axpy_head(f32x16 (&g)[NT], const WBuf &wb, uint32_t vec, float s) {
-    asm volatile("" : "+s"(vec));
-    f32x4 va[4], vb[4];
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) va[gq] = wload(wb, wb.h16, (vec + (gq * 2) * 4) * 4);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x4(&cur)[4] = (t & 1) ? vb : va;
-        f32x4(&nxt)[4] = (t & 1) ? va : vb;
-        if (t + 1 < NT) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) nxt[gq] = wload(wb, wb.h16, (vec + (((t + 1) * 4 + gq) * 2) * 4) * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) g[t][4 * gq + i] = fmaf(cur[gq][i], s, g[t][4 * gq + i]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
+                    const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
+                    hipStream_t st);      // mlp_bf16.hip
 
 struct DgradArgs {
     NetPlan plan;
@@ -712,7 +670,7 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                           const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256,
-                          bool x3 = false) {
+                          bool x3 = false, const void *packed_bwd_x3 = nullptr) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
@@ -735,6 +693,11 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     const int64_t ntiles = (n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;
+    int x3rc = NRF_ERR_UNSUPPORTED;
+    if (x3 && packed_bwd_x3 && !want_gx && time_ch == 0)   // the chain on the bf16 matrix pipe, where a kernel exists
+        x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st);
+    if (x3rc != NRF_OK && x3rc != NRF_ERR_UNSUPPORTED) return x3rc;
+    if (x3rc == NRF_OK) goto dgrad_done;
     switch (want_gx ? -nt : nt) {
         case 8: hipLaunchKernelGGL(dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, d); break;
         case 4: hipLaunchKernelGGL(dgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, d); break;
@@ -744,6 +707,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
         case -2: hipLaunchKernelGGL((dgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, d); break;
         default: return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: W = %d has no fused kernel", W);
     }
+dgrad_done:
     int rc = check_launch("nrf_query_bwd (dgrad)");
     if (rc) return rc;
     if (want_gx) {
@@ -819,11 +783,13 @@ extern "C" int nrf_query_bwd_input(const nrf_net_t *net, const nrf_embed_t *emb,
     return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream);
 }
 
-extern "C" int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
-                                    const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
-                                    const float *pts, float *g_pts, void *stream) {
+extern "C" int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed,
+                                    const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf,
+                                    float *slab, int64_t n_points, const nrf_net_t *grads, const float *pts, float *g_pts,
+                                    void *stream) {
     NRF_REQUIRE((pts == nullptr) == (g_pts == nullptr), "nrf_query_bwd_bf16x3: pts and g_pts go together");
-    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream, 256, true);
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream, 256, true,
+                          packed_bwd_x3);
 }
 
 extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,

@@ -499,6 +499,53 @@ __device__ __forceinline__ void store_in_t8(const TBuf &tb, uint32_t sec, const 
                                               (int)((sec + 2 * s * 8) * 4), 0);
 }
 
+// ---- pieces of the backward chain shared by the f32 (mlp_bwd.hip) and bf16x3 (mlp_bf16.hip) dgrad kernels
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[t][r] = 0.0f;
+}
+
+// head tile: 32 channels starting at channel c0 of a section with C channels; channel c0+o = vals[o] (o < n), else 0
+__device__ __forceinline__ void store_head_tile(const TBuf &tb, uint32_t sec, int C, int c0, const float (&vals)[8],
+                                                int n) {
+    const int voff = ((tb.m * C + c0 + 16 * tb.h) * 8 + tb.q7) * 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (tb.h == 0 && j == o && o < n) v = vals[o];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), tb.rsrc, voff, (int)((sec + j * 8) * 4), 0);
+    }
+}
+
+// g[t][r] += vec[channel] * s   (head weight vectors in accumulator order), loads one tile ahead
+template <int NT>
+__device__ __forceinline__ void axpy_head(f32x16 (&g)[NT], const WBuf &wb, uint32_t vec, float s) {
+    asm volatile("" : "+s"(vec));
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) va[gq] = wload(wb, wb.h16, (vec + (gq * 2) * 4) * 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4(&cur)[4] = (t & 1) ? vb : va;
+        f32x4(&nxt)[4] = (t & 1) ? va : vb;
+        if (t + 1 < NT) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) nxt[gq] = wload(wb, wb.h16, (vec + (((t + 1) * 4 + gq) * 2) * 4) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[t][4 * gq + i] = fmaf(cur[gq][i], s, g[t][4 * gq + i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __device__ __forceinline__ float pow2i(int f) { return __int_as_float((127 + f) << 23); }
 
 // sin and cos of one encoder argument, |a| <= kSincosMax (every frequency of a scene-sized coordinate: x * 2^9 with

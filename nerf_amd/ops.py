@@ -308,7 +308,8 @@ class PackedNet:
             if pts is not None:
                 pts = _f32(pts, "pts")
                 g_pts = torch.empty((n_points, 3), device=dev, dtype=torch.float32)
-            check(lib.nrf_query_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw), _ptr(acts),
+            check(lib.nrf_query_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
+                                           _ptr(self.bwd_x3_stream() if x3 != "wgrad" else None), _ptr(g_raw), _ptr(acts),
                                            _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _ptr(pts), _ptr(g_pts),
                                            _stream()), "nrf_query_bwd_bf16x3")
             return grads if pts is None else (grads, g_pts)
@@ -325,6 +326,23 @@ class PackedNet:
 
     def _bwd_fn(self):
         return _lib.lib().nrf_query_bwd
+
+    def bwd_x3_stream(self):
+        """W^T stream of the bf16x3 activation-gradient chain, repacked with the f32 copy; None where the shape has no
+        bf16x3 kernel (the library then runs that chain in f32)."""
+        if self.emb.mode != 0 or self.net.W not in (128, 256) or self.net.D < 2:
+            return None
+        if getattr(self, "_bwd_x3_versions", None) != self._versions or getattr(self, "_bwd_x3", None) is None:
+            lib = _lib.lib()
+            nb = lib.nrf_mlp_bf16x3_bwd_packed_bytes(C.byref(self.net), C.byref(self.emb))
+            if nb <= 0:
+                return None
+            if getattr(self, "_bwd_x3", None) is None or self._bwd_x3.numel() != nb:
+                self._bwd_x3 = torch.empty((nb,), device=self.packed.device, dtype=torch.uint8)
+            check(lib.nrf_mlp_bf16x3_bwd_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self._bwd_x3), _stream()),
+                  "nrf_mlp_bf16x3_bwd_pack_weights")
+            self._bwd_x3_versions = self._versions
+        return self._bwd_x3
 
 
 class PackedTimeNet(PackedNet):

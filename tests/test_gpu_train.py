@@ -254,7 +254,10 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
         assert d <= 1e-2 * max(float(grads_a[k].double().norm()), 1e-12), (k, d)
     # nrf_query_bwd_bf16x3 on the SAME workspace (identical gates): only the weight-gradient GEMMs change arithmetic, so
     # the agreement is the arithmetic's own -- 5e-5 of each gradient's scale
-    grads_c = f32.query_bwd(g_raw, P, acts_a, x3=True)
-    for k in grads_a:
-        sc = max(float(grads_a[k].abs().max()), 1e-12)
-        assert float((grads_a[k] - grads_c[k]).abs().max()) <= 5e-5 * sc, (k, float((grads_a[k] - grads_c[k]).abs().max()), sc)
+    # ("wgrad": the weight-gradient GEMMs alone; True: the activation-gradient chain on the bf16 pipe as well)
+    for mode in ("wgrad", True):
+        grads_c = f32.query_bwd(g_raw, P, acts_a, x3=mode)
+        for k in grads_a:
+            sc = max(float(grads_a[k].abs().max()), 1e-12)
+            e = float((grads_a[k] - grads_c[k]).abs().max())
+            assert e <= 5e-5 * sc, (mode, k, e, sc)
