@@ -12,7 +12,7 @@ FWD_FLOP_PER_POINT = 1186816
 STEP_FLOP_PER_POINT = 2 * 1744512   # fwd + dgrad + wgrad, SURVEY 8d
 
 
-def step_traffic():
+def step_traffic(workload="train"):
     """HBM bytes per training step summed over this library's kernels, from the committed PMC passes."""
     import glob
     import os
@@ -20,7 +20,7 @@ def step_traffic():
     if not files:
         return None
     try:
-        t = json.load(open(files[-1]))["train"]
+        t = json.load(open(files[-1]))[workload]
         return sum(v["launches"] * v["hbm_bytes"] for k, v in t.items() if isinstance(v, dict) and "hbm_bytes" in v) \
             / t["_steps_profiled"]
     except (KeyError, ValueError):
@@ -29,7 +29,7 @@ def step_traffic():
 
 def run_train(args, torch, dist, world, rank, device, emit=True):
     import nerf_fixtures as fx
-    from bench import PEAK_F32_MFMA_TFLOPS, build_nets
+    from bench import PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS, build_nets
     from nerf_amd import parallel
     from nerf_amd.positional_encoding import get_embedder
     from nerf_amd.render import render, run_network
@@ -100,6 +100,9 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
     if rank == 0:
         pts = n_global * 256
         achieved = (pts / world) * STEP_FLOP_PER_POINT * args.steps / dt / 1e12      # per GPU: the roofline is one GPU's
+        # bf16x3 issues three bf16 MFMAs per f32 product: in f32-equivalent FLOP/s its matrix roofline is a third of the bf16 peak
+        peak = PEAK_F32_MFMA_TFLOPS if tprec == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3
+        traffic = step_traffic("train" if tprec == "fp32" else "train_bf16x3")
         out = {
             "metric": "rays/sec at 64+128 samples/ray (train step)",
             "value": n_global * args.steps / dt,
@@ -110,10 +113,14 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
                                    f"{tprec}, forward+backward+Adam", "global_batch_rays": n_global,
                        "parallelism": f"dp{world}, two gradient buckets (fine, coarse: 2.38 MB each), the first all-reduce "
                                       "overlapped with the coarse net's backward" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": step_traffic(),
-                         "kernel": "whole step (query_fwd<train> + dgrad + wgrad kernels), per GPU; algorithmic "
-                                   "3.489 MFLOP/point over wall time; traffic = HBM bytes per 4096-ray STEP over all kernels"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         # the step also moves ~10 KB/point of saved activations and gradients each way: its HBM side
+                         "hbm_frac_of_8TBs": (traffic / (dt / args.steps) / 8e12) if traffic and world == 1 else None,
+                         "kernel": ("whole step (query_fwd<train> + dgrad + wgrad kernels)" if tprec == "fp32" else
+                                    "whole step (query_fwd_bf16x3<train> + dgrad_x3 + wgrad<x3> kernels; FLOP/s f32-equivalent, "
+                                    "peak = bf16 peak / 3)") + ", per GPU; algorithmic 3.489 MFLOP/point over wall time; "
+                                   "traffic = HBM bytes per 4096-ray STEP over all kernels"},
         }
         out.update(mg)
         if emit:
