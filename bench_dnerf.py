@@ -122,7 +122,7 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
 TRAIN_MAC = 3 * (TIME_MAC + OCC_MAC) - ((63 + 21) * 256 + 63 * 256) - 27 * 128
 
 
-def run_dnerf_train(args, torch, device, n_rays=1024, steps=10, warmup=3):
+def run_dnerf_train(args, torch, device, n_rays=1024, steps=10, warmup=3, train_precision="fp32"):
     """One D-NeRF training step as vanilla_dynamic/train.py:237-277 runs it (bouncingballs_deform.txt: N_rand 1024,
     64+128 samples, one DNeRF_Deformation for both passes, grad_clip 1.0): render_dnerf on a ray batch with per-ray
     times -> mse(rgb) + mse(rgb0) -> backward through the canonical net into the deformation net -> clipped fused Adam.
@@ -142,6 +142,7 @@ def run_dnerf_train(args, torch, device, n_rays=1024, steps=10, warmup=3):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(device)
     model.embed_fn = embed_fn
+    model.train_precision = train_precision
     params = list(model.parameters())
     opt = FusedAdam(params, lr=5e-4, betas=(0.9, 0.999))
     qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
@@ -175,7 +176,9 @@ def run_dnerf_train(args, torch, device, n_rays=1024, steps=10, warmup=3):
     dt = (time.perf_counter() - t0) / steps
     pts = n_rays * (64 + 192)
     tf = pts * 2 * TRAIN_MAC / dt / 1e12
-    return {"value": n_rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
-            "roofline_frac": tf / PEAK_F32_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+    return {"value": n_rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt,
+            "dtype": "f32" if train_precision == "fp32" else "f32 chains + bf16x3 canonical forward and weight gradients",
+            # mixed arithmetic has no single matrix roofline: the fraction is quoted for the exact-f32 step only
+            "roofline_frac": tf / PEAK_F32_MFMA_TFLOPS if train_precision == "fp32" else None, "achieved_TFLOPs": tf,
             "workload": f"D-NeRF deformation training step, {n_rays}-ray batch with per-ray times, 64+128 samples, time net + "
                         "canonical net D=8 W=256, fp32, forward+backward+clipped fused Adam"}

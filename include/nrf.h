@@ -191,6 +191,12 @@ int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const 
                        const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                        void *stream);
 
+/* nrf_dnerf_time_bwd with the weight-gradient GEMMs on the bf16x3 arithmetic (see nrf_query_bwd_bf16x3 below); the
+ * activation-gradient chain of the deformation net runs on the exact f32 kernel. */
+int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time, const float *g_dx,
+                              const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                              void *stream);
+
 /* ---- bf16x3: the same query at f32-grade accuracy on the bf16 matrix pipe (no counterpart in the reference).
  * Every f32 operand is carried as hi = bf16(v), lo = bf16(v - hi); a product is the three MFMAs Wh*xh + Wh*xl + Wl*xh
  * accumulated in f32.  Raw outputs agree with the f32 kernel to ~1e-5 of their scale (bf16: 5e-3), rendered values to the

@@ -792,6 +792,15 @@ extern "C" int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb
                           packed_bwd_x3);
 }
 
+extern "C" int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
+                                         const float *g_dx, const float *acts, float *gbuf, float *slab, int64_t n_points,
+                                         const nrf_net_t *grads, void *stream) {
+    NRF_REQUIRE(time_net && !time_net->use_viewdirs && time_net->input_ch_views > 0,
+                "nrf_dnerf_time_bwd_bf16x3: not a time-net descriptor");
+    return query_bwd_impl(time_net, emb, time_net->input_ch_views, packed_time, g_dx, acts, gbuf, slab, n_points, grads,
+                          nullptr, nullptr, stream, 256, true);
+}
+
 extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
                                   const float *g_dx, const float *acts, float *gbuf, float *slab, int64_t n_points,
                                   const nrf_net_t *grads, void *stream) {

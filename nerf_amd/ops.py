@@ -301,9 +301,12 @@ class PackedNet:
             gn.rgb_w, gn.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
         else:
             gn.out_w, gn.out_b = g("output_linear.weight"), g("output_linear.bias")
+        if x3 and self._bwd_fn() is not lib.nrf_query_bwd:      # deformation net: weight-gradient GEMMs on the bf16 pipe
+            check(lib.nrf_dnerf_time_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw),
+                                                _ptr(acts), _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()),
+                  "nrf_dnerf_time_bwd_bf16x3")
+            return grads
         if x3:
-            if self._bwd_fn() is not lib.nrf_query_bwd:
-                raise NotImplementedError("the bf16x3 backward is built for NeRF-shaped nets, not the deformation net")
             g_pts = None
             if pts is not None:
                 pts = _f32(pts, "pts")

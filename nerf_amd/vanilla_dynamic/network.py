@@ -37,7 +37,15 @@ class _DeformFunction(torch.autograd.Function):
         skip = (t_pt[first] == 0.0) if module.zero_canonical else torch.zeros(P, dtype=torch.bool, device=pts.device)
         dx = torch.where(skip[:, None], torch.zeros_like(dx), dx)
         x2 = pts + dx
-        raw, acts_c = occ.query_train(x2, viewdirs, pts_per_ray)
+        # train_precision "bf16x3": the canonical net's forward and every weight-gradient GEMM as three bf16 MFMAs per
+        # product; the deformation net's forward and both activation-gradient chains (which carry d/dx) stay exact f32
+        x3 = module.train_precision == "bf16x3" and module.W in (128, 256) and module.W_deform in (128, 256)
+        if module.train_precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', not {module.train_precision!r}")
+        occ.refresh()
+        fwd = module._occ._packed((0, L, Lv, "bf16x3")) if x3 else occ
+        raw, acts_c = fwd.query_train(x2, viewdirs, pts_per_ray)
+        ctx.x3 = x3
         ctx.module, ctx.keys, ctx.n_points = module, (L, Lv, Lt), P
         ctx.versions = (tnet._versions, occ._versions)
         ctx.save_for_backward(acts_t, acts_c, x2, skip)
@@ -55,10 +63,10 @@ class _DeformFunction(torch.autograd.Function):
                                "the packed weights no longer match the saved activations")
         if g_raw is None:
             g_raw = torch.zeros((ctx.n_points, 4), device=x2.device)
-        g_occ, g_x2 = occ.query_bwd(g_raw.contiguous(), ctx.n_points, acts_c, pts=x2)
+        g_occ, g_x2 = occ.query_bwd(g_raw.contiguous(), ctx.n_points, acts_c, pts=x2, x3="wgrad" if ctx.x3 else False)
         g_dx = g_x2 if g_dx_out is None else g_x2 + g_dx_out
         g_dx = torch.where(skip[:, None], torch.zeros_like(g_dx), g_dx)
-        g_time = tnet.query_bwd(g_dx.contiguous(), ctx.n_points, acts_t)
+        g_time = tnet.query_bwd(g_dx.contiguous(), ctx.n_points, acts_t, x3="wgrad" if ctx.x3 else False)
         out = []
         for name, _ in module.named_parameters():
             if name.startswith("_occ."):
@@ -193,6 +201,7 @@ class DNeRF_Deformation(nn.Module):
         # product, f32-grade results); the last two are inference only.  An attribute, not a constructor argument of
         # the reference
         self.precision = "fp32"
+        self.train_precision = "fp32"     # "bf16x3": see _DeformFunction.forward
 
     def _apply(self, fn, *args, **kwargs):
         self._packed_time = None
