@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
                 // monotonicity check (rank-merge below needs a sorted list)
                 float left = __shfl_up(out, 1);
                 if (lane == 0) left = prev_last;
-                if (j < ns && out < left) sorted_ok = false;
+                if (j < ns && !(out >= left)) sorted_ok = false;   // NaN compares false: non-finite rows take the sort path
                 prev_last = __shfl(out, 63);
             }
             sorted_ok = __all(sorted_ok);
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) sample_fine_kernel(const float *__restric
             bool zsorted = true;
             if (live) {
                 for (int i = lane; i + 1 < S; i += 64)
-                    if (m.merged[i + 1] < m.merged[i]) zsorted = false;
+                    if (!(m.merged[i + 1] >= m.merged[i])) zsorted = false;   // (so every output slot is written)
                 zsorted = __all(zsorted);
             }
             const bool fast = live && sorted_ok && zsorted;  // wave-uniform

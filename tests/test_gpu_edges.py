@@ -74,3 +74,27 @@ def test_cpu_tensors_are_refused(net):
         ops.composite_fwd(torch.zeros(2, 4, 4), torch.zeros(2, 4).cuda(), torch.zeros(2, 3).cuda())
     with pytest.raises(RuntimeError, match="GPU tensor"):
         net.query_points(torch.zeros(4, 3), torch.zeros(4, 3).cuda(), 1, 10, 4)
+
+
+def test_non_finite_rows_still_fill_every_merged_slot():
+    """A ray whose coarse weights (or depths) hold NaN / Inf: the resampler's outputs for it are garbage, as in the
+    reference, but EVERY slot of its merged row is written (such rows take the sort path; comparisons with NaN are false
+    and would otherwise pass the rank-merge's monotonicity checks) and its neighbours are untouched."""
+    import ctypes as C
+    from nerf_amd import _lib, ops
+    rays = dev(fx.blender_rays(6, 5))
+    z = ops.sample_coarse(rays, 64)
+    rng = np.random.RandomState(2)
+    w = dev(np.abs(rng.normal(size=(6, 64))))
+    _, ref, _ = ops.sample_fine(z, w, 128, None, want_samples=False)
+    w_bad, z_bad = w.clone(), z.clone()
+    w_bad[1, 10] = float("nan")
+    w_bad[3, 5] = float("inf")
+    z_bad[4, 20] = float("nan")
+    merged = torch.full((6, 192), 12345.0, device="cuda")
+    std = torch.empty(6, device="cuda")
+    _lib.check(_lib.lib().nrf_sample_fine(ops._ptr(z_bad), ops._ptr(w_bad), 6, 64, 128, None, None, ops._ptr(merged),
+                                          ops._ptr(std), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nrf_sample_fine")
+    assert not bool((merged == 12345.0).any())
+    for r in (0, 2, 5):
+        assert torch.equal(merged[r], ref[r])
