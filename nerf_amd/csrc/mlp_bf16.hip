@@ -291,9 +291,7 @@ struct WStreamT {
     // covers part of every stall instead of idling through four in a row).
     __device__ __forceinline__ void publish() {
         // the copies of chunks beyond the next one (4 per chunk and wave, returned in order) may stay in flight
-        if (kStages == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (kStages == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 3) * 4) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
