@@ -75,8 +75,12 @@ struct BfLayer {
     int64_t dst;   // byte offset in the stream
 };
 
-// one thread = one lane's 16 bytes (8 bf16) of one A fragment
-__global__ void pack_bf16_kernel(BfLayer a, char *stream) {
+// one thread = one lane's 16 bytes (8 bf16) of one A fragment; blockIdx.y picks the layer of the batch (a training step
+// repacks three streams per net after every optimizer step: one launch per 16 layers instead of one per layer)
+constexpr int kPackBatch = 16;
+struct BfPackBatch { BfLayer layer[kPackBatch]; };
+__global__ void pack_bf16_kernel(BfPackBatch batch, char *stream) {
+    const BfLayer &a = batch.layer[blockIdx.y];
     int ks_total = 0;
     for (int i = 0; i < a.nblk; ++i) ks_total += a.blk[i].ksteps;
     const int64_t nthreads = (int64_t)ks_total * a.nt_out * 64 * (a.split ? 2 : 1);
@@ -216,7 +220,9 @@ static void bf_plan_net_bwd(BfPlan &P, const nrf_net_t *net) {
     }
 }
 
-__global__ void pack_bias_kernel(BfBiasEntry e, float *table) {
+struct BfBiasBatch { BfBiasEntry e[8]; };
+__global__ void pack_bias_kernel(BfBiasBatch b, float *table) {
+    const BfBiasEntry &e = b.e[blockIdx.x];
     if ((int)threadIdx.x < e.n) table[e.dst + threadIdx.x] = e.src[threadIdx.x];
 }
 
@@ -225,13 +231,20 @@ static int64_t bf_total_bytes(const BfPlan &P) { return P.bytes + kBiasTable * 4
 static int bf_pack(const BfPlan &P, void *packed, hipStream_t st) {
     if (hipMemsetAsync(packed, 0, bf_total_bytes(P), st) != hipSuccess)
         return nrf::fail(NRF_ERR_LAUNCH, "bf16 pack: hipMemsetAsync failed");
-    for (int i = 0; i < P.n; ++i) {
-        const BfLayer &L = P.layer[i];
-        if (!L.W || !L.b) return nrf::fail(NRF_ERR_INVALID, "bf16 pack: a parameter pointer of the net is null (layer %d)", i);
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3(128), dim3(256), 0, st, L, (char *)packed);
+    for (int i = 0; i < P.n; ++i)
+        if (!P.layer[i].W || !P.layer[i].b)
+            return nrf::fail(NRF_ERR_INVALID, "bf16 pack: a parameter pointer of the net is null (layer %d)", i);
+    for (int i0 = 0; i0 < P.n; i0 += kPackBatch) {
+        BfPackBatch b{};
+        const int nb = P.n - i0 < kPackBatch ? P.n - i0 : kPackBatch;
+        for (int i = 0; i < nb; ++i) b.layer[i] = P.layer[i0 + i];
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(32, nb), dim3(256), 0, st, b, (char *)packed);
     }
-    for (int i = 0; i < P.nbias; ++i)
-        hipLaunchKernelGGL(pack_bias_kernel, dim3(1), dim3(64), 0, st, P.bias[i], (float *)((char *)packed + P.bytes));
+    if (P.nbias > 0) {
+        BfBiasBatch bb{};
+        for (int i = 0; i < P.nbias; ++i) bb.e[i] = P.bias[i];
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(P.nbias), dim3(64), 0, st, bb, (float *)((char *)packed + P.bytes));
+    }
     return check_launch("nrf_mlp_bf16_pack_weights");
 }
 
