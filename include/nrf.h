@@ -41,7 +41,7 @@ const char *nrf_last_error_string(void);
 typedef struct {
     int32_t D, W, input_ch, input_ch_views, output_ch, use_viewdirs;
     int32_t skips_mask;   /* bit i set <=> i in skips (network.py:52) */
-    int32_t reserved;
+    int32_t reserved;     /* input_ch_time of a DNeRF_Straightforward descriptor (nrf_dnerf_straight_*), else 0 */
     const float *pts_w[NRF_MAX_D];
     const float *pts_b[NRF_MAX_D];
     const float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b;
@@ -167,6 +167,18 @@ int nrf_dnerf_query_fwd(const nrf_net_t *time_net, const nrf_net_t *occ_net, con
                         const float *packed_time, const float *packed_occ, const float *pts, const float *viewdirs,
                         const float *times, int64_t n_points, int32_t pts_per_ray, int32_t times_per_point,
                         int64_t netchunk, int32_t zero_canonical, float *raw, float *dx, void *stream);
+
+/* DNeRF_Straightforward -- vanilla_dynamic/network.py:100-196: NeRF.forward with cat[gamma(x), gamma(t)] as trunk input and
+ * as skip (layer 0 reads input_ch + input_ch_time columns, the layer after a skip input_ch + input_ch_time + W), view head
+ * as network.py:179-189.  net->reserved = input_ch_time; emb->multires_time = L of get_time_embedder.
+ * mode 0: pts [P,3], viewdirs [P/pts_per_ray,3], times [P/pts_per_ray] (or [P] when times_per_point).
+ * mode 1 (what forward(x, ts) receives): pts = x [P, input_ch + input_ch_views] embedded, times = ts [P, input_ch_time]
+ * embedded.  raw [P,4].  Inference (the reference's own run_network_dnerf cannot call this network type at HEAD). */
+int64_t nrf_dnerf_straight_packed_floats(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_dnerf_straight_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, float *packed, void *stream);
+int nrf_dnerf_straight_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                                 const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                 int32_t times_per_point, float *raw, void *stream);
 
 /* ---- bf16 MFMA variant of the network query (BASELINE north star: "optional bf16 variant"; no counterpart in the
  * reference, which is fp32 only).  Same arguments and results as nrf_query_fwd with embed mode 0, computed with

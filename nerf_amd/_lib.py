@@ -80,6 +80,10 @@ _SIGS = {
                                      C.POINTER(NrfNet), vp]),
     "nrf_dnerf_time_bwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
                                             C.POINTER(NrfNet), vp]),
+    "nrf_dnerf_straight_packed_floats": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
+    "nrf_dnerf_straight_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
+    "nrf_dnerf_straight_query_fwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, C.c_int64, C.c_int32,
+                                               C.c_int32, vp, vp]),
     "nrf_gen_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int32, vp,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float,
                                C.c_float, vp, vp]),

@@ -111,7 +111,9 @@ struct Planner {
 
 // Builds the plan for one NeRF-shaped net.  time_ch > 0: deformation ("_time") net whose first layer
 // also takes gamma(t) (vanilla_dynamic/network.py:254-305) and whose head is out_w/out_b (W -> 3).
-static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t *emb, int time_ch) {
+// straight: DNeRF_Straightforward (vanilla_dynamic/network.py:100-196) -- a NeRF whose trunk input AND skip are
+// cat[gamma(x), gamma(t)], with the usual view head.
+static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, bool straight = false) {
     NetPlan &pl = P.plan;
     const int W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
     if (W < 32 || W > 256 || W % 32) return "W must be a multiple of 32 in [32, 256]";
@@ -119,12 +121,16 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     // a skip index >= D never fires in the reference's loop (network.py:49-53) and is ignored here too; index D - 1
     // would widen the trunk's output, which the reference's heads cannot take either
     if ((net->skips_mask >> (D - 1)) & 1) return "a skip at the last trunk layer is not supported (nor by the reference)";
-    const bool views = net->use_viewdirs != 0 && time_ch == 0;
+    const bool views = net->use_viewdirs != 0 && (time_ch == 0 || straight);
+    if (straight && time_ch <= 0) return "a straightforward net needs time channels";
+    if (straight && __builtin_popcount((unsigned)net->skips_mask & ((1u << (D - 1)) - 1u)) > 1)
+        return "the fused straightforward kernel takes one skip layer";
+    pl.straight = straight;
     if (views && (W / 2) % 32) return "use_viewdirs needs W/2 to be a multiple of 32";
     pl.nt = W / 32;
     pl.n_trunk = D;
     pl.use_viewdirs = views;
-    pl.output_ch = time_ch ? 3 : (views ? 4 : net->output_ch);
+    pl.output_ch = (time_ch && !straight) ? 3 : (views ? 4 : net->output_ch);
     if (pl.output_ch < 1 || pl.output_ch > kMaxHeadOut) return "output_ch must be in [1, 8]";
     if (emb->mode == 0) {
         if (ic != 3 + 6 * emb->multires || emb->multires < 0 || emb->multires > 10)
@@ -160,19 +166,22 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
         pl.l0_b = P.bias(net->pts_b[0], W, nt);
     }
     pl.trunk_base = P.cur;
-    pl.trunk_stride = nt * 32 + 4 * nt * nt * 256 + (kKsX / 4) * nt * 256;
+    pl.trunk_stride = nt * 32 + 4 * nt * nt * 256 + (kKsX / 4) * nt * 256 + (straight ? (kKsT / 4) * nt * 256 : 0);
     pl.skip_in_mask = 0;
+    const int skip_ch = ic + (straight ? time_ch : 0);   // channels a skip layer reads ahead of the hidden ones
     for (int i = 1; i < D; ++i) {
         bool skip = (net->skips_mask >> (i - 1)) & 1;  // network.py:52-53: layer i reads cat[input_pts, h]
-        int ld = W + (skip ? ic : 0);
+        int ld = W + (skip ? skip_ch : 0);
         int64_t slot = P.cur;
         P.bias(net->pts_b[i], W, nt);
-        P.gemm_block(net->pts_w[i], ld, W, nt, BLK_HIDDEN, 0, 16 * nt, skip ? ic : 0);
+        P.gemm_block(net->pts_w[i], ld, W, nt, BLK_HIDDEN, 0, 16 * nt, skip ? skip_ch : 0);
         if (skip) {
             pl.skip_in_mask |= 1 << i;
             P.gemm_block(net->pts_w[i], ld, W, nt, pl.x_type, pl.x_param, kKsX, 0);
+            if (straight) P.gemm_block(net->pts_w[i], ld, W, nt, pl.t_type, pl.t_param, kKsT, ic);
         } else {
             P.zeros((kKsX / 4) * nt * 256);
+            if (straight) P.zeros((kKsT / 4) * nt * 256);
         }
         if (P.cur - slot != pl.trunk_stride) return "internal: trunk slot size mismatch";
     }
@@ -192,7 +201,7 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     pl.trunkT_stride = 4 * nt * nt * 256;
     for (int i = 1; i < D; ++i) {
         bool skip = (net->skips_mask >> (i - 1)) & 1;
-        P.gemm_block_T(net->pts_w[i], W + (skip ? ic : 0), skip ? ic : 0, W, nt, W, nt);
+        P.gemm_block_T(net->pts_w[i], W + (skip ? skip_ch : 0), skip ? skip_ch : 0, W, nt, W, nt);
     }
     if (views) {
         pl.featT_w = P.gemm_block_T(net->feature_w, W, 0, W, nt, W, nt);

@@ -13,6 +13,7 @@
 //   * sin/cos use the accurate range-reducing device functions (arguments reach ~3000 rad).
 // The kernel is MFMA-bound: 593 920 MAC per point issued (593 408 algorithmic, 99.9 %).
 #include <array>
+#include <type_traits>
 
 #include "mlp_device.h"
 
@@ -29,10 +30,12 @@ struct QueryArgs {
     float *acts;            // training mode: [n_tiles][tl.a_tile] saved inputs / activations (T8 sections)
     TrainLayout tl;
     const float *times;     // deformation ("time") net: [P / t_div] scalar input of the second layer-0 block
-    int64_t t_div;
+    int64_t t_div;          // (straightforward net with embedded inputs: rows [P, t_stride] of gamma(t), t_div = 1)
+    int32_t t_stride, pad2_;
 };
 
-template <int NT, bool EMB, bool TRAIN, bool TIME = false>
+// STRAIGHT: DNeRF_Straightforward -- the time block also feeds the skip layers (so it stays live through the trunk)
+template <int NT, bool EMB, bool TRAIN, bool TIME = false, bool STRAIGHT = false>
 __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
     const NetPlan &pl = a.plan;
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -46,6 +49,7 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t ntiles = (a.n_points + 31) >> 5;
     const uint32_t hid_off = NT * 32, skip_off = NT * 32 + 4 * NT * NT * 256;
+    const uint32_t skipt_off = skip_off + (kKsX / 4) * NT * 256;
 
     for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
         const int64_t p = tile * 32 + n;
@@ -69,7 +73,8 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
         gemm_in<kKsX, NT>(acc, xin, wb, (uint32_t)pl.l0_w);
         if constexpr (TIME) {   // vanilla_dynamic/network.py:296: h = cat[gamma(x), gamma(t)]
             float tin[kKsT];
-            fill_pe1<kKsT>(tin, a.times[pc / a.t_div], pl.t_param, h);
+            if constexpr (EMB) fill_raw<kKsT>(tin, a.times + pc * a.t_stride, pl.t_param, h);
+            else fill_pe1<kKsT>(tin, a.times[pc / a.t_div], pl.t_param, h);
             if constexpr (TRAIN) store_in_t8<kKsT>(tb, (uint32_t)a.tl.a_tin, tin);
             gemm_in<kKsT, NT>(acc, tin, wb, (uint32_t)pl.l0_w2);
         }
@@ -90,12 +95,29 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 gate_bits_group<NT>(tb, slot, hin, lane, reinterpret_cast<uint32_t(&)[4]>(*m.data()), G);
             };
         };
-        for (int l = 1; l < pl.n_trunk; ++l) {
+        // one trunk layer l >= 1; WITH_T (straightforward nets): its skip also reads gamma(t), network.py:176-177
+        auto trunk_layer = [&](int l, auto with_t) {
             const uint32_t slot = (uint32_t)(pl.trunk_base + (int64_t)(l - 1) * pl.trunk_stride);   // acc holds its bias
             if ((pl.skip_in_mask >> l) & 1) gemm_in<kKsX, NT>(acc, xin, wb, slot + skip_off);
+            if constexpr (decltype(with_t)::value) {   // gamma(t) is rebuilt here: 12 registers the trunk cannot keep live
+                float tin[kKsT];
+                if constexpr (EMB) fill_raw<kKsT>(tin, a.times + pc * a.t_stride, pl.t_param, h);
+                else fill_pe1<kKsT>(tin, a.times[pc / a.t_div], pl.t_param, h);
+                gemm_in<kKsT, NT>(acc, tin, wb, slot + skipt_off);
+            }
             if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, slot + hid_off, save_hin(l - 1));
             else gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
             relu_move_bias<NT>(hin, acc, wb, bias_after(l));
+        };
+        if constexpr (STRAIGHT) {
+            // the time block sits in straight-line code between two plain layer loops (inside the loop, under a runtime
+            // condition, the register allocator gave up: 1100 spilled registers); one skip layer, as every shipped config
+            const int ls = 31 - __builtin_clz((unsigned)pl.skip_in_mask | 1u);      // the skip layer (0: none)
+            for (int l = 1; l < ls; ++l) trunk_layer(l, std::false_type{});
+            if (ls >= 1) trunk_layer(ls, std::true_type{});
+            for (int l = (ls >= 1 ? ls + 1 : 1); l < pl.n_trunk; ++l) trunk_layer(l, std::false_type{});
+        } else {
+            for (int l = 1; l < pl.n_trunk; ++l) trunk_layer(l, std::false_type{});
         }
         if (pl.use_viewdirs) {
             if constexpr (NT >= 2) {
@@ -157,6 +179,10 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
     int64_t ntiles = (a.n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // 512 registers per lane -> one 4-wave workgroup per CU
+    if (a.plan.straight) {
+        hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
+        return check_launch("nrf_dnerf_straight_query_fwd");
+    }
     if constexpr (!EMB) {
         if (a.times) {
             hipLaunchKernelGGL((query_fwd_kernel<NT, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
@@ -196,18 +222,19 @@ extern "C" int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb
 
 static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
                           const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
-                          void *stream, const float *times = nullptr, int64_t t_div = 1) {
+                          void *stream, const float *times = nullptr, int64_t t_div = 1, bool straight = false) {
     NRF_REQUIRE(net && emb, "nrf_query_fwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_fwd: negative n_points");
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
                 "nrf_query_fwd: packed and raw must be 16-byte aligned");
     Planner P{};
-    const char *e = plan_net(P, net, emb, times ? net->input_ch_views : 0);
+    const char *e = straight ? plan_net(P, net, emb, net->reserved, true)
+                             : plan_net(P, net, emb, times ? net->input_ch_views : 0);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: %s", e);
     if (n_points == 0) return NRF_OK;
     QueryArgs a{};
-    a.times = times; a.t_div = t_div;
+    a.times = times; a.t_div = t_div; a.t_stride = straight ? net->reserved : 1;
     a.plan = P.plan;
     a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.raw = raw; a.n_points = n_points;
     a.input_ch = net->input_ch;
@@ -262,4 +289,36 @@ extern "C" int nrf_dnerf_time_fwd_train(const nrf_net_t *time_net, const nrf_emb
     NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0, "nrf_dnerf_time_fwd_train: n_points must be a multiple of pts_per_ray");
     return query_fwd_impl(time_net, emb, packed_time, pts, nullptr, n_points, pts_per_ray, dx, acts, stream, times,
                           times_per_point ? 1 : pts_per_ray);
+}
+
+/* DNeRF_Straightforward (vanilla_dynamic/network.py:100-196): a NeRF whose trunk input and skip are cat[gamma(x), gamma(t)].
+ * net->reserved carries the time channel count (input_ch_time).  Inference. */
+extern "C" int64_t nrf_dnerf_straight_packed_floats(const nrf_net_t *net, const nrf_embed_t *emb) {
+    if (!net || !emb) return -1;
+    Planner P{};
+    const char *e = plan_net(P, net, emb, net->reserved, true);
+    if (e) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_packed_floats: %s", e); return -1; }
+    return P.plan.total_floats;
+}
+
+extern "C" int nrf_dnerf_straight_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, float *packed, void *stream) {
+    NRF_REQUIRE(net && emb && packed, "nrf_dnerf_straight_pack_weights: null pointer");
+    Planner P{};
+    const char *e = plan_net(P, net, emb, net->reserved, true);
+    if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_pack_weights: %s", e);
+    for (int i = 0; i < P.pack.nsec; ++i)
+        NRF_REQUIRE(P.pack.sec[i].src || P.pack.sec[i].kind == 4,
+                    "nrf_dnerf_straight_pack_weights: a parameter pointer of the net is null (section %d)", i);
+    hipLaunchKernelGGL(pack_kernel, dim3(64, P.pack.nsec), dim3(256), 0, as_stream(stream), P.pack, packed);
+    return check_launch("nrf_dnerf_straight_pack_weights");
+}
+
+extern "C" int nrf_dnerf_straight_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                                            const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                            int32_t times_per_point, float *raw, void *stream) {
+    NRF_REQUIRE(net && emb, "nrf_dnerf_straight_query_fwd: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(times, "nrf_dnerf_straight_query_fwd: times is null");
+    NRF_REQUIRE(net->use_viewdirs, "nrf_dnerf_straight_query_fwd: the fused kernel needs use_viewdirs");
+    return query_fwd_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, nullptr, stream, times,
+                          emb->mode != 0 || times_per_point ? 1 : pts_per_ray, true);
 }

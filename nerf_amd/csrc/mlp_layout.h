@@ -83,7 +83,8 @@ struct NetPlan {
     int32_t skip_in_mask;  // bit l set <=> trunk layer l also consumes the position input block
     int32_t use_viewdirs, output_ch;
     int32_t x_type, x_param, d_type, d_param, t_type, t_param;   // input block kinds
-    int32_t pad_;
+    int32_t straight;    // DNeRF_Straightforward: skip layers read cat[gamma(x), gamma(t), h]; the trunk slots then carry a
+                         // time block after the position block (trunk_stride grows by (kKsT / 4) * nt * 256)
     int64_t l0_w, l0_w2, l0_b;          // layer 0: position block, time block (D-NeRF), bias
     int64_t trunk_base, trunk_stride;   // slot of layer l >= 1: trunk_base + (l-1)*trunk_stride
     int64_t feat_w, feat_b;             // feature_linear (network.py:57)

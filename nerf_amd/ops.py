@@ -399,6 +399,57 @@ class PackedTimeNet(PackedNet):
         return _lib.lib().nrf_dnerf_time_bwd
 
 
+class PackedStraightNet(PackedNet):
+    """DNeRF_Straightforward (vanilla_dynamic/network.py:100-196) behind nrf_dnerf_straight_*: NeRF-shaped parameters whose
+    trunk input and skip are cat[gamma(x), gamma(t)].  mode 1 = the embedded rows forward(x, ts) receives."""
+
+    def __init__(self, params, D, W, input_ch, input_ch_views, input_ch_time, skips, mode=1, multires=0, multires_views=0,
+                 multires_time=0):
+        self.params = params
+        self.net = NrfNet()
+        n = self.net
+        n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch, n.use_viewdirs = D, W, input_ch, input_ch_views, 4, 1
+        n.reserved = input_ch_time
+        n.skips_mask = sum(1 << int(s) for s in skips)
+        self.emb = NrfEmbed(mode, multires, multires_views, multires_time)
+        self.n_floats = _lib.lib().nrf_dnerf_straight_packed_floats(C.byref(n), C.byref(self.emb))
+        if self.n_floats <= 0:
+            raise RuntimeError("nrf_dnerf_straight_packed_floats: " + _lib.lib().nrf_last_error_string().decode())
+        self.packed = None
+        self._versions = None
+        self.out_ch = 4
+
+    def refresh(self):
+        vers = tuple((v.data_ptr(), v._version) for v in self.params.values())
+        if self.packed is not None and vers == self._versions:
+            return
+        self._fill_pointers()
+        dev = next(iter(self._p.values())).device
+        if self.packed is None or self.packed.device != dev:
+            self.packed = torch.empty((self.n_floats,), device=dev, dtype=torch.float32)
+        check(_lib.lib().nrf_dnerf_straight_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()),
+              "nrf_dnerf_straight_pack_weights")
+        self._versions = vers
+
+    def query(self, pts, viewdirs, times, pts_per_ray=1, times_per_point=True):
+        """mode 1: pts = x [P, input_ch + input_ch_views], times = ts [P, input_ch_time] (both embedded), viewdirs None.
+        mode 0: pts [P,3], viewdirs [P/pts_per_ray,3], times [P/pts_per_ray] or [P]."""
+        self.refresh()
+        pts, times = _f32(pts, "pts"), _f32(times, "times")
+        P = pts.shape[0]
+        raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
+        if viewdirs is not None:
+            viewdirs = _f32(viewdirs, "viewdirs")
+        check(_lib.lib().nrf_dnerf_straight_query_fwd(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                                      _ptr(viewdirs), _ptr(times), P, int(pts_per_ray),
+                                                      int(bool(times_per_point)), _ptr(raw), _stream()),
+              "nrf_dnerf_straight_query_fwd")
+        return raw
+
+    def query_train(self, *a, **k):
+        raise NotImplementedError("the fused straightforward kernel is inference only; training composes GPU torch ops")
+
+
 class PackedNetBf16(PackedNet):
     """bf16 weight stream of a NeRF module for nrf_query_fwd_bf16 (raw points + in-kernel encoding only)."""
 

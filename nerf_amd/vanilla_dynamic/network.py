@@ -133,7 +133,9 @@ class NeRF(_StaticNeRF):
 class DNeRF_Straightforward(nn.Module):
     """cat[gamma(x), gamma(t)] -> NeRF-shaped MLP (network.py:100-196).  NB: at the reference's HEAD this
     network type cannot be rendered (run_network_dnerf passes pts_raw=/t_raw= which this forward does not
-    accept); the class is kept for construction / checkpoint parity and evaluates with torch ops."""
+    accept), but forward(x, ts) itself is callable: without gradients it runs the fused f32 kernel on the
+    embedded rows (nrf_dnerf_straight_query_fwd, embed mode 1); with gradients, or for shapes the kernel does not take, the
+    same arithmetic composed from GPU torch ops.  Both pinned to the reference's outputs (tests/golden/dnerf2.npz)."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, input_ch_time=1, output_ch=4, skips=[4],
                  use_viewdirs=True):
@@ -151,9 +153,28 @@ class DNeRF_Straightforward(nn.Module):
             self.rgb_linear = nn.Linear(W // 2, 3)
         else:
             self.output_linear = nn.Linear(W, output_ch)
+        self._packed = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _fusable(self, x, t_embed):
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or t_embed.requires_grad
+                                                 or any(p.requires_grad for p in self.parameters()))
+        return (x.is_cuda and not need_grad and self.use_viewdirs and self.W in (64, 128, 256) and self.D <= 16
+                and self.input_ch <= 64 and self.input_ch_views <= 32 and self.input_ch_time <= 24
+                and (self.D - 1) not in self.skips and len([s for s in self.skips if s < self.D - 1]) <= 1)
 
     def forward(self, x, ts):
         t_embed = ts[0] if isinstance(ts, (list, tuple)) else ts
+        if self._fusable(x, t_embed):
+            if self._packed is None:
+                params = {k: v for k, v in self.named_parameters()}
+                self._packed = ops.PackedStraightNet(params, self.D, self.W, self.input_ch, self.input_ch_views,
+                                                     self.input_ch_time, [s for s in self.skips if s < self.D - 1])
+            out = self._packed.query(x.reshape(-1, x.shape[-1]), None, t_embed.reshape(-1, t_embed.shape[-1]))
+            return out, torch.zeros_like(x[:, :3])
         input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
         xt = torch.cat([input_pts, t_embed], dim=-1)
         h = xt

@@ -383,8 +383,23 @@ def test_straightforward_vs_reference(d2, dparts):
     with torch.no_grad():
         xin = torch.cat([embed_fn(pts), embeddirs_fn(dirs)], -1)
         te = embed_time(tt)
-    out, dx = m(xin, [te, te])
+    with torch.no_grad():          # inference: the fused f32 kernel on the embedded rows (nrf_dnerf_straight_query_fwd)
+        fused, dxf = m(xin, [te, te])
+    assert m._packed is not None, "the fused path did not run"
+    np.testing.assert_allclose(host(fused), d2["sf_out"], atol=2e-5 * np.abs(d2["sf_out"]).max(), rtol=0)
+    assert dxf.shape == (320, 3) and float(dxf.abs().max()) == 0.0
+    out, dx = m(xin, [te, te])     # with gradients: the torch composition
     np.testing.assert_allclose(host(out), d2["sf_out"], atol=1e-5, rtol=0)
     assert dx.shape == (320, 3) and float(dx.abs().max()) == 0.0
     (out * dev(d2["sf_gw"])).sum().backward()
     check_grads(m.named_parameters(), d2, "sf_grad_")
+    # a W = 128 instantiation with another skip position, ragged point count: fused vs composed
+    m2 = vd.DNeRF_Straightforward(D=5, W=128, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4, skips=[1],
+                                  use_viewdirs=True)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_straightforward_state(62, D=5, W=128, skips=(1,)).items()})
+    m2 = m2.cuda()
+    with torch.no_grad():
+        a, _ = m2(xin[:77], te[:77])
+        m2._fusable = lambda *args: False
+        b, _ = m2(xin[:77], te[:77])
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
