@@ -46,6 +46,13 @@ typedef struct {
     const float *pts_b[NRF_MAX_D];
     const float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b;
     const float *out_w, *out_b; /* output_linear (use_viewdirs == 0) */
+    /* LayerNorm variant (vanilla_dynamic/network.py:46-48, :75-76, :88-89, :276-300): nn.LayerNorm(W) after every trunk
+     * Linear (weight / bias of pts_layernorms[i], or of _time_layernorms[i] for a time-net descriptor) and nn.LayerNorm(W/2)
+     * after the view layer.  use_layernorm == 0: the pointers are ignored.  Forward (inference) only; eps = 1e-5. */
+    int32_t use_layernorm, reserved2;
+    const float *ln_w[NRF_MAX_D];
+    const float *ln_b[NRF_MAX_D];
+    const float *views_ln_w, *views_ln_b;
 } nrf_net_t;
 
 /* how the query kernel obtains the network input */

@@ -18,7 +18,9 @@ class NrfNet(C.Structure):
                 ("pts_w", vp * MAX_D), ("pts_b", vp * MAX_D),
                 ("views_w", vp), ("views_b", vp), ("feature_w", vp), ("feature_b", vp),
                 ("alpha_w", vp), ("alpha_b", vp), ("rgb_w", vp), ("rgb_b", vp),
-                ("out_w", vp), ("out_b", vp)]
+                ("out_w", vp), ("out_b", vp),
+                ("use_layernorm", C.c_int32), ("reserved2", C.c_int32),
+                ("ln_w", vp * MAX_D), ("ln_b", vp * MAX_D), ("views_ln_w", vp), ("views_ln_b", vp)]
 
 
 class NrfEmbed(C.Structure):

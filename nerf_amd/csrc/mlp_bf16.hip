@@ -152,6 +152,7 @@ constexpr int kHbOut = 0, kHbAlpha = 8, kHbRgb = 9, kHbTime = 32;
 
 static const char *bf_check_net(const nrf_net_t *net, const nrf_embed_t *emb, bool time_net) {
     if (emb->mode != 0) return "the bf16 kernels take raw points (embed mode 0) only";
+    if (net->use_layernorm) return "LayerNorm nets run on the f32 kernels only";
     if (net->W != 128 && net->W != 256) return "the bf16 kernels are built for W = 128 and 256";
     if (net->D < 1 || net->D > NRF_MAX_D) return "D out of range";
     if (emb->multires < 0 || emb->multires > 10 || net->input_ch != 3 + 6 * emb->multires)

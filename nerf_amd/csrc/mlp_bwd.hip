@@ -677,6 +677,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     Planner P{};
     const char *e = plan_net(P, net, emb, time_ch);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: %s", e);
+    if (P.plan.layernorm) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: LayerNorm nets have no fused backward");
     if (n_points == 0) return NRF_OK;
     const bool want_gx = g_pts != nullptr;
     if (want_gx) {

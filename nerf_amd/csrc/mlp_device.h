@@ -196,6 +196,20 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     } else {
         P.head(net->out_w, net->out_b, W, pl.output_ch, nt, 0, pl.out_vec, pl.out_b);               // network.py:67
     }
+    pl.layernorm = net->use_layernorm != 0;
+    if (pl.layernorm) {   // vanilla_dynamic/network.py:46-48 (or :275-277 for the time net): affine parameters in bias order
+        pl.ln_base = P.cur;
+        pl.ln_stride = 2 * nt * 32;
+        for (int i = 0; i < D; ++i) {
+            P.bias(net->ln_w[i], W, nt);
+            P.bias(net->ln_b[i], W, nt);
+        }
+        if (views) {
+            pl.views_ln = P.cur;
+            P.bias(net->views_ln_w, W / 2, nt / 2);
+            P.bias(net->views_ln_b, W / 2, nt / 2);
+        }
+    }
     // W^T blocks for the backward chain (dgrad): hidden parts only (inputs need no gradient here)
     pl.trunkT_base = P.cur;
     pl.trunkT_stride = 4 * nt * nt * 256;
@@ -327,6 +341,47 @@ __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)
                 dst[t][r] = v;
             }
         }
+}
+
+// LayerNorm over the 32 * NT channels of each point + ReLU, on the way out of the accumulators (vanilla_dynamic/network.py:
+// 75-77): a lane holds 16 * NT of its point's channels, lane ^ 32 the others, so the two row statistics (mean, then the
+// centred variance: biased, eps = 1e-5, as nn.LayerNorm) are lane-local sums finished by one cross-half shuffle each.
+// `ln` = offset of (weight, bias) in bias order.  dst may alias src.
+template <int NT>
+__device__ __forceinline__ void ln_relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], const WBuf &wb, uint32_t ln) {
+    constexpr float inv_n = 1.0f / (32 * NT);
+    asm volatile("" : "+s"(ln));
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += src[t][r];
+    const float mean = (s + __shfl_xor(s, 32)) * inv_n;
+    float v = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = src[t][r] - mean;
+            v = fmaf(d, d, v);
+        }
+    const float rstd = 1.0f / sqrtf((v + __shfl_xor(v, 32)) * inv_n + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 w[4], b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            w[g] = wload(wb, wb.h16, (ln + ((t * 4 + g) * 2) * 4) * 4);
+            b[g] = wload(wb, wb.h16, (ln + NT * 32 + ((t * 4 + g) * 2) * 4) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float y = fmaf((src[t][r] - mean) * rstd, w[r >> 2][r & 3], b[r >> 2][r & 3]);
+            dst[t][r] = fmaxf(y, 0.0f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // relu_move with the NEXT layer's bias loads folded in: as soon as tile t has left the accumulator file its

@@ -160,6 +160,9 @@ extern "C" int nrf_dnerf_query_fwd(const nrf_net_t *time_net, const nrf_net_t *o
     if (!Pc.plan.use_viewdirs) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_query_fwd: canonical net must use view directions");
     if (Pt.plan.nt != Pc.plan.nt)
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_query_fwd: time and canonical nets must have the same width");
+    if (Pt.plan.layernorm || Pc.plan.layernorm)
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_query_fwd: LayerNorm nets run as nrf_dnerf_time_fwd_train + "
+                                              "nrf_query_fwd (the single-launch chain has no normalisation stage)");
     if (n_points == 0) return NRF_OK;
     DnerfArgs a{};
     a.tplan = Pt.plan; a.cplan = Pc.plan;

@@ -35,7 +35,9 @@ struct QueryArgs {
 };
 
 // STRAIGHT: DNeRF_Straightforward -- the time block also feeds the skip layers (so it stays live through the trunk)
-template <int NT, bool EMB, bool TRAIN, bool TIME = false, bool STRAIGHT = false>
+// LN: the use_layernorm variant (vanilla_dynamic/network.py:46-48): LayerNorm between every trunk Linear and its ReLU, and
+// after the view layer; inference
+template <int NT, bool EMB, bool TRAIN, bool TIME = false, bool STRAIGHT = false, bool LN = false>
 __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
     const NetPlan &pl = a.plan;
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -84,7 +86,16 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             if (l + 1 < pl.n_trunk) return (uint32_t)(pl.trunk_base + (int64_t)l * pl.trunk_stride);
             return pl.use_viewdirs ? (uint32_t)pl.feat_b : (uint32_t)pl.l0_b;
         };
-        relu_move_bias<NT>(hin, acc, wb, bias_after(0));
+        // out of the accumulators: ReLU (LN: LayerNorm first), and the next layer's bias goes in
+        auto activate = [&](int l) {
+            if constexpr (LN) {
+                ln_relu_move<NT>(hin, acc, wb, (uint32_t)(pl.ln_base + (int64_t)l * pl.ln_stride));
+                load_bias<NT>(acc, wb, bias_after(l));
+            } else {
+                relu_move_bias<NT>(hin, acc, wb, bias_after(l));
+            }
+        };
+        activate(0);
         // TRAIN: a layer's activations (and their ReLU gate bits) are saved by the GEMM that consumes them, four
         // registers per k-group under that group's MFMAs (save_hin); only a layer with no consumer saves in a burst
         auto save_hin = [&](int l) {
@@ -107,7 +118,7 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             }
             if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, slot + hid_off, save_hin(l - 1));
             else gemm_hid<NT, NT>(acc, hin, wb, slot + hid_off);
-            relu_move_bias<NT>(hin, acc, wb, bias_after(l));
+            activate(l);
         };
         if constexpr (STRAIGHT) {
             // the time block sits in straight-line code between two plain layer loops (inside the loop, under a runtime
@@ -147,7 +158,8 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 }
                 if constexpr (TRAIN) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
                 gemm_in<kKsD, NT / 2>(acc2, din, wb, (uint32_t)pl.views_w_in);
-                relu_move<NT / 2>(acc2, acc2, true);
+                if constexpr (LN) ln_relu_move<NT / 2>(acc2, acc2, wb, (uint32_t)pl.views_ln);       // network.py:88-90
+                else relu_move<NT / 2>(acc2, acc2, true);
                 if constexpr (TRAIN) {
                     store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);
                     store_gate_bits<NT / 2>(tb, (uint32_t)a.tl.a_mask + pl.n_trunk * 256, acc2, lane);
@@ -182,6 +194,16 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
     if (a.plan.straight) {
         hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
         return check_launch("nrf_dnerf_straight_query_fwd");
+    }
+    if (a.plan.layernorm) {   // inference kernels; the time net's goes through its training entry point (acts are written)
+        if constexpr (!EMB) {
+            if (a.times) {
+                hipLaunchKernelGGL((query_fwd_kernel<NT, false, true, true, false, true>), dim3(blocks), dim3(256), 0, st, a);
+                return check_launch("nrf_dnerf_time_fwd_train (LayerNorm)");
+            }
+        }
+        hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false, false, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        return check_launch("nrf_query_fwd (LayerNorm)");
     }
     if constexpr (!EMB) {
         if (a.times) {
@@ -232,6 +254,8 @@ static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const fl
     const char *e = straight ? plan_net(P, net, emb, net->reserved, true)
                              : plan_net(P, net, emb, times ? net->input_ch_views : 0);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: %s", e);
+    if (P.plan.layernorm && acts && !times)
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd_train: LayerNorm nets have no fused training kernels");
     if (n_points == 0) return NRF_OK;
     QueryArgs a{};
     a.times = times; a.t_div = t_div; a.t_stride = straight ? net->reserved : 1;

@@ -96,6 +96,9 @@ struct NetPlan {
     int64_t featT_w, viewsT_w;          // W^T of feature_linear; of views_linears[0][:, :W]
     int64_t xT_base, xT_stride;         // W[:, :input_ch]^T of the layers that read the position block (layer 0, skip
                                         // layers, in layer order): input gradients for the D-NeRF chain; -1 if absent
+    int64_t ln_base, ln_stride;         // LayerNorm (weight, bias) of trunk layer l in bias order: ln_base + l*ln_stride, +nt*32
+    int64_t views_ln;                   // the view layer's (weight, bias): views_ln, + (nt/2)*32
+    int32_t layernorm, pad2_;
     int64_t total_floats;
 };
 

@@ -219,6 +219,7 @@ class PackedNet:
         n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch = D, W, input_ch, input_ch_views, output_ch
         n.use_viewdirs = int(bool(use_viewdirs))
         n.skips_mask = sum(1 << int(s) for s in skips)
+        n.use_layernorm = int(any("layernorm" in k for k in params))
         self.emb = NrfEmbed(mode, multires, multires_views, multires_time)
         self.n_floats = _lib.lib().nrf_mlp_packed_floats(C.byref(n), C.byref(self.emb))
         if self.n_floats <= 0:
@@ -240,6 +241,11 @@ class PackedNet:
             n.rgb_w, n.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
         else:
             n.out_w, n.out_b = g("output_linear.weight"), g("output_linear.bias")
+        if n.use_layernorm:       # vanilla_dynamic/network.py:46-48
+            for i in range(n.D):
+                n.ln_w[i], n.ln_b[i] = g(f"pts_layernorms.{i}.weight"), g(f"pts_layernorms.{i}.bias")
+            if n.use_viewdirs:
+                n.views_ln_w, n.views_ln_b = g("views_layernorm.weight"), g("views_layernorm.bias")
 
     def refresh(self):
         vers = tuple((v.data_ptr(), v._version) for v in self.params.values())
@@ -359,6 +365,7 @@ class PackedTimeNet(PackedNet):
         n = self.net
         n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch, n.use_viewdirs = D, W, input_ch, input_ch_time, 3, 0
         n.skips_mask = sum(1 << int(s) for s in skips)
+        n.use_layernorm = int(any("layernorm" in k for k in params))     # `_time_layernorms` as pts_layernorms.{i}.*
         self.emb = NrfEmbed(0, multires, 0, multires_time)
         self.n_floats = _lib.lib().nrf_dnerf_time_packed_floats(C.byref(n), C.byref(self.emb))
         if self.n_floats <= 0:
@@ -461,6 +468,7 @@ class PackedNetBf16(PackedNet):
         n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch = D, W, input_ch, input_ch_views, output_ch
         n.use_viewdirs = int(bool(use_viewdirs))
         n.skips_mask = sum(1 << int(s) for s in skips)
+        n.use_layernorm = int(any("layernorm" in k for k in params))      # refused by the library: f32 kernels only
         self.emb = NrfEmbed(0, multires, multires_views, 0)
         self.n_bytes = _lib.lib().nrf_mlp_bf16_packed_bytes(C.byref(n), C.byref(self.emb))
         if self.n_bytes <= 0:

@@ -104,18 +104,31 @@ class NeRF(_StaticNeRF):
             self.views_layernorm = nn.LayerNorm(W // 2)
 
     def _pack_params(self):
-        return {k: v for k, v in super()._pack_params().items() if "layernorm" not in k}
+        params = super()._pack_params()
+        if not self.use_viewdirs:
+            params = {k: v for k, v in params.items() if not k.startswith("views_layernorm")}
+        return params
+
+    def _ln_fused(self, x):
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return x.is_cuda and not need_grad and self.W in (64, 128, 256)
 
     def forward(self, x, ts=None):
-        if self.use_layernorm:
+        if self.use_layernorm and not self._ln_fused(x):
             out = self._forward_layernorm(x)
         else:
-            out = super().forward(x)
+            out = super().forward(x)      # the fused f32 kernel; use_layernorm: its LayerNorm instantiation (inference)
         return out, torch.zeros_like(x[:, :3])
 
+    def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
+        if self.use_layernorm and self._need_grad(pts):
+            raise RuntimeError("nerf_amd: LayerNorm nets train through forward() (GPU torch composition); the fused "
+                               "query has no LayerNorm backward")
+        return super().query_points(pts, viewdirs, pts_per_ray, multires, multires_views)
+
     def _forward_layernorm(self, x):
-        # LayerNorm variant (network.py:46-48, :75-76, :88-89): plain torch ops on the GPU -- the fused
-        # kernels have no normalisation stage.
+        # LayerNorm variant (network.py:46-48, :75-76, :88-89) from GPU torch ops: what training differentiates (the fused
+        # kernels normalise in the forward only), and the fallback for widths without a fused kernel.
         input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
         h = input_pts
         for i in range(self.D):
@@ -230,6 +243,9 @@ class DNeRF_Deformation(nn.Module):
         self._time_net = None
         return super()._apply(fn, *args, **kwargs)
 
+    def _training_call(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     # ------------------------------------------------------------------ fused path
     def _time_desc(self, L, Lt):
         n = _lib.NrfNet()
@@ -266,6 +282,9 @@ class DNeRF_Deformation(nn.Module):
             for i, l in enumerate(self._time):
                 params[f"pts_linears.{i}.weight"], params[f"pts_linears.{i}.bias"] = l.weight, l.bias
             params["output_linear.weight"], params["output_linear.bias"] = self._time_out.weight, self._time_out.bias
+            if self._time_layernorms is not None:
+                for i, ln in enumerate(self._time_layernorms):
+                    params[f"pts_layernorms.{i}.weight"], params[f"pts_layernorms.{i}.bias"] = ln.weight, ln.bias
             self._time_net = ops.PackedTimeNet(params, self.D_deform, self.W_deform, self.input_ch, self.input_ch_time,
                                                list(self.skips_deform), L, Lt)
             self._time_net_key = key
@@ -329,10 +348,21 @@ class DNeRF_Deformation(nn.Module):
                      multires_time):
         """Fused deformation chain on raw inputs: pts [P,3], viewdirs [P/pts_per_ray,3], times [P] or
         [P/pts_per_ray] -> (raw [P,4], dx [P,3])."""
-        if self.use_layernorm or not self.use_viewdirs:
-            raise RuntimeError("nerf_amd: the fused deformation kernel needs use_viewdirs=True, use_layernorm=False")
+        if not self.use_viewdirs:
+            raise RuntimeError("nerf_amd: the fused deformation kernel needs use_viewdirs=True")
         pts, viewdirs = ops._f32(pts, "pts"), ops._f32(viewdirs, "viewdirs")
         times = ops._f32(times, "times").reshape(-1)
+        if self.use_layernorm:
+            # network.py:276-300 + :46-48: both nets normalise between Linear and ReLU.  Inference runs the chain as its
+            # two halves on the LayerNorm instantiations of the f32 query kernel; training differentiates forward()'s
+            # GPU torch composition
+            if self._training_call():
+                raise RuntimeError("nerf_amd: use_layernorm nets train through forward(); the fused kernels have no "
+                                   "LayerNorm backward")
+            if self.precision != "fp32":
+                raise ValueError(f"nerf_amd: precision {self.precision!r} is not built for use_layernorm nets (fp32 only)")
+            return self._query_points_two_launch(pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
+                                                 int(netchunk), multires, multires_views, multires_time)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: exact f32 kernels with saved activations (whatever `precision` says)
             if pts.requires_grad or times.requires_grad:
@@ -373,7 +403,9 @@ class DNeRF_Deformation(nn.Module):
         from ..positional_encoding import _EmbedFn
         ef = self.embed_fn
         return (pts_raw is not None and t_raw is not None and isinstance(ef, _EmbedFn) and ef.fusable
-                and ef.out_dim == self.input_ch and not self.use_layernorm and self.use_viewdirs
+                and ef.out_dim == self.input_ch and self.use_viewdirs
+                and not (self.use_layernorm and (self._training_call() or self.W_deform not in (64, 128, 256)
+                                                 or self.W not in (64, 128, 256)))
                 and (self.input_ch_views - 3) % 6 == 0 and (self.input_ch_time - 1) % 2 == 0
                 and (self.input_ch_views - 3) // 6 <= 4 and (self.input_ch_time - 1) // 2 <= 10
                 and x.is_cuda)

@@ -35,7 +35,8 @@ def batchify(fn, chunk, is_dynamic=True):
 
 
 def _fusable(fn, embed_fn, embeddirs_fn, embed_time_fn, viewdirs):
-    if not isinstance(fn, DNeRF_Deformation) or fn.use_layernorm or not fn.use_viewdirs or viewdirs is None:
+    if not isinstance(fn, DNeRF_Deformation) or not fn.use_viewdirs or viewdirs is None \
+            or (fn.use_layernorm and fn._training_call()):
         return False
     for e, ch, lmax in ((embed_fn, fn.input_ch, 10), (embeddirs_fn, fn.input_ch_views, 4),
                         (embed_time_fn, fn.input_ch_time, 10)):

@@ -188,7 +188,8 @@ def test_train_gradients_vs_reference(gold_dnerf, parts):
 
 
 def test_layernorm_variant_runs(parts):
-    """use_layernorm=True has no fused kernel: composed from torch ops + the same reference-keyed parameters."""
+    """use_layernorm=True: reference-keyed parameters; training composes GPU torch ops, inference runs the LayerNorm
+    instantiations of the fused f32 kernel (tests/test_gpu_wellcond.py pins both to the reference)."""
     vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
     m = vd.DNeRF_Deformation(D=2, W=64, D_deform=2, W_deform=64, input_ch=63, input_ch_views=27, input_ch_time=21,
                              skips=[4], use_layernorm=True).cuda()

@@ -359,9 +359,20 @@ def test_layernorm_networks_vs_reference(d2, dparts, tag, D, W, skips, seed):
     with torch.no_grad():
         xin = torch.cat([embed_fn(pts), embeddirs_fn(dirs)], -1)
         o, z = m._occ(xin)
+    # no gradients: the LayerNorm instantiation of the fused f32 kernel on the embedded rows
+    assert m._occ._packed_cache, "the fused LayerNorm kernel did not run"
     np.testing.assert_allclose(host(o), d2[f"ln_{tag}_occ_out"], atol=2e-5, rtol=0)
     assert float(z.abs().max()) == 0.0
     te = embed_time(tt)
+    with torch.no_grad():        # the whole chain fused: time-net launch (LayerNorm) -> x + dx -> canonical launch
+        fo, fdx = m(xin, [te, te], pts_raw=pts, t_raw=tt)
+        assert m._time_net is not None, "the fused deformation path did not run"
+        co, cdx = m._forward_torch(xin, [te, te], pts, tt)        # the same chain composed from GPU torch ops
+    np.testing.assert_allclose(host(fdx), d2[f"ln_{tag}_dx"], atol=2e-5, rtol=0)
+    ref = d2[f"ln_{tag}_out"]
+    np.testing.assert_allclose(host(fo), ref, atol=1e-3 * max(1.0, np.abs(ref).max()), rtol=0)
+    print(f"LayerNorm {tag}: fused vs golden dx {np.abs(host(fdx) - d2[f'ln_{tag}_dx']).max():.2e}, out "
+          f"{np.abs(host(fo) - ref).max():.2e}; composed vs golden out {np.abs(host(co) - ref).max():.2e}")
     m.zero_grad()
     out, dx = m(xin, [te, te], pts_raw=pts, t_raw=tt)
     np.testing.assert_allclose(host(dx), d2[f"ln_{tag}_dx"], atol=2e-5, rtol=0)
@@ -370,6 +381,33 @@ def test_layernorm_networks_vs_reference(d2, dparts, tag, D, W, skips, seed):
     ((out * dev(d2[f"ln_{tag}_gw"])).sum() + (dx * dev(d2[f"ln_{tag}_gd"])).sum()).backward()
     worst = check_grads(m.named_parameters(), d2, f"ln_{tag}_grad_")
     print(f"LayerNorm {tag}: worst gradient-norm error {worst:.2e}")
+
+
+def test_layernorm_fused_other_shapes_and_refusals(dparts):
+    """W = 128 / no view directions / ragged point counts: the fused LayerNorm kernels against the GPU torch composition of
+    the same module; what the fused path does not build (bf16 arithmetic, the backward) fails loudly."""
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time) = dparts
+    rs = np.random.RandomState(5)
+    for W, D, skips, views, n in ((128, 4, [2], True, 77), (64, 2, [], False, 33), (256, 3, [0], True, 1)):
+        net = vd.NeRF(D=D, W=W, input_ch=63, input_ch_views=27, output_ch=5, skips=skips, use_viewdirs=views,
+                      use_layernorm=True).cuda()
+        with torch.no_grad():
+            for ln in list(net.pts_layernorms) + [net.views_layernorm]:
+                ln.weight.copy_(dev(rs.uniform(0.5, 1.5, ln.weight.shape)))
+                ln.bias.copy_(dev(rs.uniform(-0.3, 0.3, ln.bias.shape)))
+            x = torch.cat([embed_fn(dev(rs.uniform(-1, 1, (n, 3)))), embeddirs_fn(dev(rs.normal(size=(n, 3))))], -1)
+            a, _ = net(x)
+            assert net._packed_cache, "the fused LayerNorm kernel did not run"
+            b = net._forward_layernorm(x)
+        assert a.shape == b.shape == (n, 4 if views else 5)
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (W, D, float((a - b).abs().max()))
+    net = vd.NeRF(D=3, W=128, input_ch=63, input_ch_views=27, skips=[1], use_viewdirs=True, use_layernorm=True).cuda()
+    pts = dev(rs.uniform(-1, 1, (64, 3)))
+    with pytest.raises(RuntimeError, match="LayerNorm"):
+        net.query_points(pts, dev(rs.normal(size=(64, 3))), 1, 10, 4)              # training query: no fused backward
+    net.precision = "bf16"
+    with torch.no_grad(), pytest.raises(RuntimeError, match="LayerNorm"):
+        net.query_points(pts, dev(rs.normal(size=(64, 3))), 1, 10, 4)
 
 
 def test_straightforward_vs_reference(d2, dparts):
