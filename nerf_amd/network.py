@@ -37,22 +37,29 @@ class _QueryFunction(torch.autograd.Function):
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
             ctx.versions = packed._versions     # the dgrad chain reads the packed copy: it must still be this one
             ctx.x3 = fwd is not packed
-            ctx.save_for_backward(acts)
+            ctx.want_gpts = bool(pts.requires_grad)
+            ctx.save_for_backward(acts, *((pts,) if ctx.want_gpts else ()))
             return raw
         return packed.query(pts, viewdirs, pts_per_ray)
 
     @staticmethod
     def backward(ctx, g_raw):
-        (acts,) = ctx.saved_tensors
+        acts = ctx.saved_tensors[0]
         packed = ctx.module._packed(ctx.key)
         if packed._versions != ctx.versions:
             # torch autograd raises the same way when a tensor saved for backward was modified in place
             raise RuntimeError("nerf_amd: a parameter of this network was modified (optimizer.step(), load_state_dict) "
                                "between the forward and this backward; the packed weights no longer match the saved "
                                "activations")
-        grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, x3=ctx.x3)
+        g_pts = None
+        if ctx.want_gpts:
+            # d(raw)/d(pts) through the in-kernel encoding (what the reference's autograd gives a caller that differentiates
+            # w.r.t. the sample positions): nrf_query_bwd_input, the chain the deformation net's training uses
+            grads, g_pts = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, pts=ctx.saved_tensors[1], x3=ctx.x3)
+        else:
+            grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, x3=ctx.x3)
         order = [name for name, _ in ctx.module.named_parameters()]
-        return (None, None, None, None, None, None) + tuple(grads.get(n) for n in order)
+        return (None, None, g_pts, None, None, None) + tuple(grads.get(n) for n in order)
 
 
 class NeRF(nn.Module):
@@ -112,13 +119,15 @@ class NeRF(nn.Module):
         self._packed_cache = {}
         return super()._apply(fn, *args, **kwargs)
 
-    def _need_grad(self, x=None):
+    def _need_grad(self, x=None, input_grad_ok=False):
         if not torch.is_grad_enabled():
             return False
         if x is not None and x.requires_grad:
-            # the fused query's backward produces PARAMETER gradients only (nrf_query_bwd_input adds d/d(pts) for the
-            # deformation chain); refusing beats silently dropping d/dx
-            raise NotImplementedError("nerf_amd: gradients w.r.t. the query points are not built for this call "
+            if input_grad_ok:
+                return True
+            # forward(x) on embedded rows differentiates w.r.t. x through _forward_autograd; anything else that reaches
+            # here would silently drop d/dx, so refuse
+            raise NotImplementedError("nerf_amd: gradients w.r.t. this input are not built for this call "
                                       "(only parameter gradients); detach the input or run under torch.no_grad()")
         return any(p.requires_grad for p in self.parameters())
 
@@ -157,7 +166,10 @@ class NeRF(nn.Module):
     def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
         """pts [P,3]; viewdirs [P/pts_per_ray, 3] or None -> raw [P, 4|output_ch] (render.py:31-56 fused)."""
         key = (0, multires, multires_views if self.use_viewdirs else 0)
-        need_grad = self._need_grad(pts)
+        if torch.is_grad_enabled() and viewdirs is not None and viewdirs.requires_grad and self.use_viewdirs:
+            raise NotImplementedError("nerf_amd: gradients w.r.t. the view directions are not built (parameters and query "
+                                      "points only); detach viewdirs")
+        need_grad = self._need_grad(pts, input_grad_ok=True)      # d/d(pts): nrf_query_bwd_input
         if self.precision in ("bf16", "bf16x3") and not need_grad:   # inference only; training stays exact f32
             key = key + (self.precision,)
         elif self.precision not in ("fp32", "bf16", "bf16x3"):

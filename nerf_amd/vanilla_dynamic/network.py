@@ -121,7 +121,7 @@ class NeRF(_StaticNeRF):
         return out, torch.zeros_like(x[:, :3])
 
     def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
-        if self.use_layernorm and self._need_grad(pts):
+        if self.use_layernorm and self._need_grad(pts, input_grad_ok=True):
             raise RuntimeError("nerf_amd: LayerNorm nets train through forward() (GPU torch composition); the fused "
                                "query has no LayerNorm backward")
         return super().query_points(pts, viewdirs, pts_per_ray, multires, multires_views)

@@ -261,3 +261,58 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
             sc = max(float(grads_a[k].abs().max()), 1e-12)
             e = float((grads_a[k] - grads_c[k]).abs().max())
             assert e <= 5e-5 * sc, (mode, k, e, sc)
+
+
+@pytest.mark.parametrize("train_precision", TRAIN_PRECISIONS)
+@pytest.mark.parametrize("views,W,D,skips,n,ppr", [(True, 256, 8, [4], 192, 64), (False, 128, 4, [1], 77, 1)])
+def test_query_point_gradients(train_precision, views, W, D, skips, n, ppr):
+    """d(raw)/d(pts) of the fused query (what the reference's autograd gives a caller that differentiates through
+    run_network w.r.t. the sample positions, run_nerf_helpers-style; network.py:46-69 + positional_encoding.py:25-36):
+    nrf_query_bwd_input behind NeRF.query_points, against autograd through the same module composed from torch ops in f64."""
+    from nerf_amd.network import NeRF
+    from nerf_amd.positional_encoding import get_embedder
+    torch.manual_seed(11)
+    net = NeRF(D=D, W=W, input_ch=39, input_ch_views=15 if views else 0, output_ch=4, skips=skips, use_viewdirs=views).cuda()
+    net.train_precision = train_precision
+    L, Lv = 6, 2                                   # moderate frequencies: the gradient is then well above f32 noise
+    e, _ = get_embedder(L, 0)
+    ev, _ = get_embedder(Lv, 0)
+    rs = np.random.RandomState(3)
+    pts = dev(rs.uniform(-1, 1, (n, 3)).astype(np.float32)).requires_grad_(True)
+    dirs = dev(rs.normal(size=(n // ppr, 3)).astype(np.float32))
+    g = dev(rs.normal(size=(n, 4)).astype(np.float32))
+    raw = net.query_points(pts, dirs if views else None, ppr, L, Lv)
+    (raw * g).sum().backward()
+    got, got_params = pts.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    # the same graph in float64 torch ops
+    net64 = NeRF(D=D, W=W, input_ch=39, input_ch_views=15 if views else 0, output_ch=4, skips=skips, use_viewdirs=views)
+    net64.load_state_dict(net.state_dict())
+    net64 = net64.cuda().double()
+    p64 = pts.detach().double().requires_grad_(True)
+
+    def emb(x, Lx):
+        parts = [x] + [f(x * 2.0 ** j) for j in range(Lx) for f in (torch.sin, torch.cos)]
+        return torch.cat(parts, -1)
+    xin = emb(p64, L)
+    if views:
+        xin = torch.cat([xin, emb(dirs.double().repeat_interleave(ppr, 0), Lv)], -1)
+    else:
+        xin = torch.cat([xin, xin[:, :0]], -1)
+    ref = net64._forward_autograd(xin)
+    np.testing.assert_allclose(raw.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=5e-5 * float(ref.detach().abs().max()))
+    (ref * g.double()).sum().backward()
+    scale = float(p64.grad.norm())
+    err = float((got.double() - p64.grad).norm()) / scale
+    print(f"d/dpts ({train_precision}, W={W}): relative error {err:.2e}")
+    # bf16x3: the forward's 1e-5 error flips a few ReLU gates (DESIGN section 9); the point gradient chain itself is f32
+    assert err <= (2e-5 if train_precision == "fp32" else 1e-2), err
+    for k, p in net64.named_parameters():
+        if p.grad is None:
+            assert k not in got_params, k
+            continue
+        e_k = float((got_params[k].double() - p.grad).norm()) / max(float(p.grad.norm()), 1e-12)
+        assert e_k <= (2e-4 if train_precision == "fp32" else 1e-2), (k, e_k)
+    # view directions: refused, not silently dropped
+    if views:
+        with pytest.raises(NotImplementedError, match="view directions"):
+            net.query_points(pts.detach(), dirs.clone().requires_grad_(True), ppr, L, Lv)
