@@ -220,16 +220,24 @@ __global__ void __launch_bounds__(256) pe3_bwd_t8_kernel(const float *gbuf, int6
 // Without the sharing each wave pulled its own 8 KiB per 64 MFMAs = 8 B/clk/CU, the per-CU load limit (measured 60 %
 // of peak); shared it is 4 B/clk/CU.  X may be the concatenation of two T8 sections (cat[h, gamma(x)] of a skip
 // layer, cat[feature, gamma(d)] of the view layer), so one launch covers a whole nn.Linear.
+struct WgradEntry {       // one nn.Linear's weight-gradient GEMM
+    float *slab;         // [nchunks][NP*KP] partial dW, then [nchunks][NP] partial db
+    int64_t g_sec;
+    int64_t a_sec[2];        // X = section 0 (k_tiles0 tiles) followed by section 1
+    int32_t Cg, Ca[2];       // channels in the T8 sections
+    int32_t n_tiles, k_tiles, k_tiles0;  // 32-channel tiles of G (rows of dW) and of X (columns)
+};
+// ALL GEMMs of a backward pass in one launch: a block is (pair, chunk), a pair = (GEMM, super-block) -- pairs sorted
+// by tile count, largest first, so the skinny super-blocks (layer 0, the skip / view slices, the heads: HBM- and
+// latency-bound) run on CUs the full 8 x 8 ones (MFMA-bound) have left, instead of each kind holding the whole chip in turn.
+constexpr int kWgEntries = 20, kWgPairs = 64;     // D <= 16 trunk layers + 3 heads; <= 4 super-blocks each, typically 1-2
 struct WgradArgs {
     const float *gbuf;   // tile stride g_tile
     const float *acts;   // tile stride a_tile
-    float *slab;         // [nchunks][NP*KP] partial dW, then [nchunks][NP] partial db
-    int64_t g_tile, a_tile, g_sec;
-    int64_t a_sec[2];        // X = section 0 (k_tiles0 tiles) followed by section 1
-    int64_t ntiles;
-    int32_t Cg, Ca[2];       // channels in the T8 sections
-    int32_t n_tiles, k_tiles, k_tiles0;  // 32-channel tiles of G (rows of dW) and of X (columns)
+    int64_t g_tile, a_tile, ntiles;
     int32_t chunk_tiles, nchunks;
+    WgradEntry e[kWgEntries];
+    uint16_t pair[kWgPairs];     // entry << 8 | super-block
 };
 
 #ifndef NRF_WG_M
@@ -391,13 +399,29 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
 }
 
 template <bool X3>
-__global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
+    // The argument block is indexed by a block-uniform value: read it where it lies, in the kernel-argument segment
+    // (constant address space -> scalar loads).  Indexing the by-value parameter made the compiler copy all 1.3 KB of it
+    // to per-lane scratch memory at the top of every workgroup.
+    typedef const WgradArgs __attribute__((address_space(4))) *ArgPtr;
+    const WgradArgs __attribute__((address_space(4))) &b = *(ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)b_arg;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int chunk = blockIdx.x;
+    const int pair = blockIdx.x / b.nchunks, chunk = blockIdx.x - pair * b.nchunks;
+    const int code = b.pair[pair];
+    const WgradEntry __attribute__((address_space(4))) &ea = b.e[code >> 8];
+    // this block's GEMM and the pass-wide fields as local scalars: read once here, not again inside the step loop
+    WgradEntry a;
+    a.slab = ea.slab; a.g_sec = ea.g_sec; a.a_sec[0] = ea.a_sec[0]; a.a_sec[1] = ea.a_sec[1];
+    a.Cg = ea.Cg; a.Ca[0] = ea.Ca[0]; a.Ca[1] = ea.Ca[1];
+    a.n_tiles = ea.n_tiles; a.k_tiles = ea.k_tiles; a.k_tiles0 = ea.k_tiles0;
+    const float *const gbuf = b.gbuf, *const acts = b.acts;
+    const int64_t g_tile = b.g_tile, a_tile = b.a_tile;
+    const int sblk = code & 255;
     const int k_sblks = (a.k_tiles + 7) >> 3;
-    const int nsb = blockIdx.y / k_sblks, ksb = blockIdx.y - nsb * k_sblks;
+    const int nsb = sblk / k_sblks, ksb = sblk - nsb * k_sblks;
     const int gn = min(8, a.n_tiles - nsb * 8), xn = min(8, a.k_tiles - ksb * 8);   // pieces of the super-block
     // the super-block's gn x xn tiles are split over the four waves as a WY x WX grid of rectangles of <= 4 x 4
     // tiles; the grid (2x2, 1x4 or 4x1) with the fewest tiles per wave wins, so skinny GEMMs (layer 0, the skip and
@@ -425,8 +449,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const int64_t t0 = (int64_t)chunk * a.chunk_tiles;
-    const int64_t t1 = min(a.ntiles, t0 + a.chunk_tiles);
+    const int64_t t0 = (int64_t)chunk * b.chunk_tiles;
+    const int64_t t1 = min(b.ntiles, t0 + b.chunk_tiles);
     constexpr int kSpt = 4 / kWgM;                 // steps per 32-point tile
     const int64_t nsteps = (t1 - t0) * kSpt;       // one step = kWgM groups of 8 points of one tile
 
@@ -435,7 +459,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
         const int64_t tile = t0 + step / kSpt;
         const int m0 = (int)(step % kSpt) * kWgM;
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(a.gbuf) + tile * a.g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
+            const_cast<float *>(gbuf) + tile * g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = wib + 4 * q;
@@ -451,7 +475,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
                 const int sec = kt >= a.k_tiles0;
                 const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
                 __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float *>(a.acts) + tile * a.a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 4, 0x00020000);
+                    const_cast<float *>(acts) + tile * a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 4, 0x00020000);
 #pragma unroll
                 for (int mm = 0; mm < kWgM; ++mm)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
@@ -500,7 +524,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs a) {
                 }
             if (k0 == 0) {
                 float v = bs[x] + __shfl_xor(bs[x], 32);
-                if (lane < 32) a.slab[(int64_t)a.nchunks * NP * KP + (int64_t)chunk * NP + 32 * (n0 + x) + lane] = v;
+                if (lane < 32) a.slab[(int64_t)b.nchunks * NP * KP + (int64_t)chunk * NP + 32 * (n0 + x) + lane] = v;
             }
         }
 }
@@ -590,8 +614,29 @@ struct Bwd {
     bool x3 = false;                       // wgrad on the bf16 matrix pipe (three bf16 MFMAs per product)
     ReduceBatch batch;
     int nbatch = 0, max_blocks = 1;
+    WgradArgs wb{};
+    int nent = 0, npairs = 0;
+    int pair_size[kWgPairs];
 
-    int flush() {   // the reductions collected so far, one launch
+    int flush() {   // the GEMMs queued so far in one launch, then their reductions in one launch
+        if (nent > 0) {
+            // largest super-blocks first (stable insertion sort: equal sizes keep layer order)
+            for (int i = 1; i < npairs; ++i) {
+                const uint16_t c = wb.pair[i];
+                const int sz = pair_size[i];
+                int j = i;
+                for (; j > 0 && pair_size[j - 1] < sz; --j) { wb.pair[j] = wb.pair[j - 1]; pair_size[j] = pair_size[j - 1]; }
+                wb.pair[j] = c; pair_size[j] = sz;
+            }
+            wb.gbuf = gbuf; wb.acts = acts; wb.g_tile = tl.g_tile; wb.a_tile = tl.a_tile; wb.ntiles = ntiles;
+            wb.chunk_tiles = chunk_tiles; wb.nchunks = nchunks;
+            const unsigned blocks = (unsigned)npairs * (unsigned)nchunks;
+            if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, wb);
+            else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, wb);
+            nent = 0; npairs = 0;
+            int rc = check_launch("nrf_query_bwd (wgrad)");
+            if (rc) return rc;
+        }
         if (nbatch == 0) return NRF_OK;
         hipLaunchKernelGGL(reduce_unpack_kernel, dim3(max_blocks, nbatch), dim3(256), 0, st, batch);
         nbatch = 0; max_blocks = 1;
@@ -602,29 +647,35 @@ struct Bwd {
     struct Dst { int row0, n_valid; const float *w; const float *b; };
     struct XPart { int64_t sec; int C, tiles, type, param, ks, k_valid, ch_off; };   // a T8 section and how its columns unpack
     int run(int64_t g_sec, int Cg, int n_tiles, const XPart *xp, int nparts, int ld, const Dst *dsts, int ndst) {
-        WgradArgs w{};
+        const int k_tiles = xp[0].tiles + (nparts > 1 ? xp[1].tiles : 0);
+        const int n_sb = (n_tiles + 7) / 8, k_sb = (k_tiles + 7) / 8;
+        if (nent == kWgEntries || npairs + n_sb * k_sb > kWgPairs || nbatch + ndst * nparts > kReduceBatch) {
+            int rc = flush();
+            if (rc) return rc;
+        }
         float *region = slab + slab_off;
-        w.gbuf = gbuf; w.acts = acts; w.slab = region;
-        w.g_tile = tl.g_tile; w.a_tile = tl.a_tile; w.g_sec = g_sec;
-        w.ntiles = ntiles; w.Cg = Cg; w.n_tiles = n_tiles;
-        w.a_sec[0] = xp[0].sec; w.Ca[0] = xp[0].C; w.k_tiles0 = xp[0].tiles; w.k_tiles = xp[0].tiles;
+        WgradEntry &w = wb.e[nent];
+        w = WgradEntry{};
+        w.slab = region; w.g_sec = g_sec; w.Cg = Cg; w.n_tiles = n_tiles;
+        w.a_sec[0] = xp[0].sec; w.Ca[0] = xp[0].C; w.k_tiles0 = xp[0].tiles; w.k_tiles = k_tiles;
         w.a_sec[1] = xp[0].sec; w.Ca[1] = xp[0].C;
-        if (nparts > 1) { w.a_sec[1] = xp[1].sec; w.Ca[1] = xp[1].C; w.k_tiles += xp[1].tiles; }
-        w.chunk_tiles = chunk_tiles; w.nchunks = nchunks;
-        const int sblks = ((n_tiles + 7) / 8) * ((w.k_tiles + 7) / 8);
-        slab_off += (int64_t)nchunks * ((int64_t)n_tiles * 32 * w.k_tiles * 32 + n_tiles * 32);
+        if (nparts > 1) { w.a_sec[1] = xp[1].sec; w.Ca[1] = xp[1].C; }
+        slab_off += (int64_t)nchunks * ((int64_t)n_tiles * 32 * k_tiles * 32 + n_tiles * 32);
         if (slab_off > slab_cap) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: slab workspace too small (internal)");
-        if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunks, sblks), dim3(256), 0, st, w);
-        else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunks, sblks), dim3(256), 0, st, w);
+        for (int sb = 0; sb < n_sb * k_sb; ++sb) {
+            const int gn = std::min(8, n_tiles - (sb / k_sb) * 8), xn = std::min(8, k_tiles - (sb % k_sb) * 8);
+            pair_size[npairs] = gn * xn;
+            wb.pair[npairs++] = (uint16_t)(nent << 8 | sb);
+        }
+        ++nent;
         for (int i = 0; i < ndst; ++i) {
             int kc = 0;
             for (int q = 0; q < nparts; ++q) {
-                if (nbatch == kReduceBatch) { int rc = flush(); if (rc) return rc; }
                 ReduceArgs &r = batch.e[nbatch++];
                 r = ReduceArgs{};
                 r.slab = region; r.dst_w = const_cast<float *>(dsts[i].w);
                 r.dst_b = q == 0 ? const_cast<float *>(dsts[i].b) : nullptr;
-                r.nchunks = nchunks; r.NP = n_tiles * 32; r.KP = w.k_tiles * 32; r.row0 = dsts[i].row0;
+                r.nchunks = nchunks; r.NP = n_tiles * 32; r.KP = k_tiles * 32; r.row0 = dsts[i].row0;
                 r.n_valid = dsts[i].n_valid; r.ld = ld; r.ch_off = xp[q].ch_off;
                 r.x_type = xp[q].type; r.x_param = xp[q].param; r.x_ks = xp[q].ks; r.k_valid = xp[q].k_valid;
                 r.kc = kc; r.kn = xp[q].tiles * 32;
@@ -633,7 +684,7 @@ struct Bwd {
                 max_blocks = std::max(max_blocks, (int)grid_for(total_q, 64, 4096));
             }
         }
-        return check_launch("nrf_query_bwd (wgrad)");
+        return NRF_OK;
     }
 };
 
@@ -641,8 +692,15 @@ struct Bwd {
 
 using namespace nrf;
 
+// Partial slabs per GEMM: every chunk costs a slab of dW bytes written and read back, so small passes take fewer (a
+// chunk keeps >= kWgChunkTiles tiles while that leaves >= 32 chunks); the count is a function of the pass size
+// alone, so gradients stay bit-reproducible.
+// Measured (one box, ms per step f32 / bf16x3): 512 rays 4.45 / 2.64 with 256 chunks -> 4.02 / 2.07; 32, 64 and 128 tiles
+// per chunk within 1 %, 256 and more slower again (too few workgroups).
+constexpr int kWgChunkTiles = 64;
 static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles, int max_chunks = 256) {
-    int64_t nchunks = ntiles < max_chunks ? ntiles : max_chunks;
+    int64_t want = std::max<int64_t>(32, ntiles / kWgChunkTiles);
+    int64_t nchunks = std::min<int64_t>(std::min<int64_t>(ntiles, max_chunks), want);
     *chunk_tiles = (int)((ntiles + nchunks - 1) / nchunks);
     return (ntiles + *chunk_tiles - 1) / *chunk_tiles;
 }
