@@ -104,6 +104,18 @@ class QueryTimer:
         return ms, pts, len(self.events)
 
 
+def _kernel_entry(table, kernel):
+    """table[kernel], or the entry whose name continues `kernel`'s template argument list (kernels gain trailing template
+    parameters between rounds: query_fwd_kernel<8, false, false, false> is ...<8, false, false, false, false, false> now)."""
+    if kernel in table:
+        return table[kernel]
+    stem = kernel[:-1] + ","
+    for k in sorted(table):
+        if k.startswith(stem):
+            return table[k]
+    raise KeyError(kernel)
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json, latest round;
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command, FETCH doubled as the
@@ -113,7 +125,7 @@ def pmc_traffic(workload, kernel):
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))[workload][kernel]["hbm_bytes"]
+        return _kernel_entry(json.load(open(files[-1]))[workload], kernel)["hbm_bytes"]
     except (KeyError, ValueError):
         return None
 
@@ -126,7 +138,7 @@ def pmc_mfma_util(workload, kernel):
     if not files:
         return {}
     try:
-        e = json.load(open(files[-1]))[workload][kernel]
+        e = _kernel_entry(json.load(open(files[-1]))[workload], kernel)
         return {"mfma_busy_frac": round(e["mfma_busy_frac"], 4), "clock_ghz": round(e.get("clock_ghz", 0.0), 3),
                 "mfma_util_source": os.path.basename(files[-1])}
     except (KeyError, ValueError):

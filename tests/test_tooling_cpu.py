@@ -69,3 +69,21 @@ def test_ray_table_golden_is_float64_rounded_once():
     assert str(g["table_dtype_before_cast"][0]) == "float64"
     H, W = g["table_hw"]
     assert g["table"].shape == (3 * H * W, 3, 3) and g["table"].dtype == np.float32
+
+
+def test_bench_finds_its_committed_counter_evidence():
+    """bench.py's roofline.traffic / mfma_busy_frac come from the committed PMC summaries: the kernel names it asks for must
+    resolve against them (kernels gain template parameters between rounds; the lookup follows the argument-list prefix)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for workload, kernel in (("render", "query_fwd_kernel<8, false, false, false>"),
+                             ("render_bf16", "query_fwd_bf16_kernel<8, true>"),
+                             ("render_bf16x3", "query_fwd_bf16x3_kernel<8, true>")):
+        t = bench.pmc_traffic(workload, kernel)
+        assert t is not None and 1e8 < t < 1e9, (workload, t)          # ~115 MB algorithmic per 4 M-point launch
+        u = bench.pmc_mfma_util(workload, kernel)
+        assert 0.5 < u["mfma_busy_frac"] < 1.0 and 1.5 < u["clock_ghz"] < 2.5, (workload, u)
+    table = {"k<1, true, false>": 1, "k<1, true, true>": 2, "j<2>": 3}
+    assert bench._kernel_entry(table, "k<1, true>") == 1 and bench._kernel_entry(table, "j<2>") == 3
