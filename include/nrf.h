@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 100
+/* bumped whenever a struct layout or a signature changes (200: nrf_net_t carries the LayerNorm parameters); a binding
+ * compares nrf_version() with the NRF_VERSION it was written against before passing structs */
+#define NRF_VERSION 200
 #define NRF_MAX_D 16
 
 typedef enum {

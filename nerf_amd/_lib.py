@@ -30,6 +30,7 @@ class NrfEmbed(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 200     # include/nrf.h NRF_VERSION
 
 _SIGS = {
     "nrf_version": (C.c_int, []),
@@ -115,6 +116,9 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        if l.nrf_version() != ABI_VERSION:      # a stale libnrf.so would read the structs below with another layout
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {l.nrf_version()}, this binding is written against "
+                               f"{ABI_VERSION} (include/nrf.h NRF_VERSION): rebuild with `make -C nerf_amd/csrc`")
         _lib = l
     return _lib
 

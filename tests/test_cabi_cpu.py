@@ -38,7 +38,11 @@ def net(D=8, W=256, ic=63, icv=27, oc=4, uv=1, skips=(4,)):
 
 def test_version_and_size_queries():
     l = _lib.lib()
-    assert l.nrf_version() == 100
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "nrf.h")).read()
+    assert l.nrf_version() == _lib.ABI_VERSION == int(re.search(r"#define NRF_VERSION (\d+)", hdr).group(1))
+    # the ctypes mirror of nrf_net_t: 8 int32, 2 x 16 + 10 pointers, 2 int32, 2 x 16 + 2 pointers (include/nrf.h)
+    assert C.sizeof(_lib.NrfNet) == 8 * 4 + (32 + 10) * 8 + 2 * 4 + (32 + 2) * 8
     n, e = net(), NrfEmbed(0, 10, 4, 0)
     floats = l.nrf_mlp_packed_floats(C.byref(n), C.byref(e))
     # forward blocks (593 920 padded MACs' worth of weights + biases/heads) + transposed hidden blocks for dgrad
