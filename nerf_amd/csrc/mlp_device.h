@@ -21,9 +21,14 @@ struct PackSec {
                         // contraction index = W's output channel (valid below n_src)
     int32_t n_src, pad_;
 };
-constexpr int kMaxSecs = 72;
+constexpr int kMaxSecs = 64;        // sections per pack launch (the table travels as a kernel argument)
+constexpr int kPlanSecs = 256;      // sections of one plan: D = 16 with LayerNorm needs ~115
 struct PackArgs {
     PackSec sec[kMaxSecs];
+    int32_t nsec;
+};
+struct PackList {
+    PackSec sec[kPlanSecs];
     int32_t nsec;
 };
 
@@ -61,7 +66,7 @@ static __global__ void __launch_bounds__(256) pack_kernel(PackArgs a, float *__r
 // host planner
 struct Planner {
     NetPlan plan;
-    PackArgs pack;
+    PackList pack;
     int64_t cur = 0;
     bool want_pack;
     const char *err = nullptr;
@@ -72,7 +77,7 @@ struct Planner {
         return o;
     }
     void add(PackSec s) {
-        if (pack.nsec >= kMaxSecs) { err = "too many weight sections"; return; }
+        if (pack.nsec >= kPlanSecs) { err = "too many weight sections"; return; }
         pack.sec[pack.nsec++] = s;
     }
     int64_t gemm_block(const float *w, int ld, int n_out, int nt_out, int type, int param, int ks, int ch_off) {
@@ -108,6 +113,20 @@ struct Planner {
         add(PackSec{nullptr, o, 4, 0, 0, 0, 0, 0, 0, 0, (int32_t)count, 0, 0, 0});
     }
 };
+
+// All sections of a plan, kMaxSecs per launch.
+static inline int launch_pack(const Planner &P, float *packed, hipStream_t st, const char *who) {
+    for (int i = 0; i < P.pack.nsec; ++i)
+        if (!P.pack.sec[i].src && P.pack.sec[i].kind != 4)
+            return nrf::fail(NRF_ERR_INVALID, "%s: a parameter pointer of the net is null (section %d)", who, i);
+    for (int i0 = 0; i0 < P.pack.nsec; i0 += kMaxSecs) {
+        PackArgs a{};
+        a.nsec = P.pack.nsec - i0 < kMaxSecs ? P.pack.nsec - i0 : kMaxSecs;
+        for (int i = 0; i < a.nsec; ++i) a.sec[i] = P.pack.sec[i0 + i];
+        hipLaunchKernelGGL(pack_kernel, dim3(64, a.nsec), dim3(256), 0, st, a, packed);
+    }
+    return check_launch(who);
+}
 
 // Builds the plan for one NeRF-shaped net.  time_ch > 0: deformation ("_time") net whose first layer
 // also takes gamma(t) (vanilla_dynamic/network.py:254-305) and whose head is out_w/out_b (W -> 3).

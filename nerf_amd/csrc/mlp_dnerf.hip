@@ -133,11 +133,7 @@ extern "C" int nrf_dnerf_pack_time_weights(const nrf_net_t *time_net, const nrf_
     Planner P{};
     const char *e = plan_time(P, time_net, emb);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_pack_time_weights: %s", e);
-    for (int i = 0; i < P.pack.nsec; ++i)
-        NRF_REQUIRE(P.pack.sec[i].src || P.pack.sec[i].kind == 4,
-                    "nrf_dnerf_pack_time_weights: a parameter pointer of the net is null (section %d)", i);
-    hipLaunchKernelGGL(pack_kernel, dim3(64, P.pack.nsec), dim3(256), 0, as_stream(stream), P.pack, packed);
-    return check_launch("nrf_dnerf_pack_time_weights");
+    return launch_pack(P, packed, as_stream(stream), "nrf_dnerf_pack_time_weights");
 }
 
 extern "C" int nrf_dnerf_query_fwd(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb,

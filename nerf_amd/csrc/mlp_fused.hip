@@ -235,11 +235,7 @@ extern "C" int nrf_mlp_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb
     Planner P{};
     const char *e = plan_net(P, net, emb, 0);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_pack_weights: %s", e);
-    for (int i = 0; i < P.pack.nsec; ++i)
-        NRF_REQUIRE(P.pack.sec[i].src || P.pack.sec[i].kind == 4,
-                    "nrf_mlp_pack_weights: a parameter pointer of the net is null (section %d)", i);
-    hipLaunchKernelGGL(pack_kernel, dim3(64, P.pack.nsec), dim3(256), 0, as_stream(stream), P.pack, packed);
-    return check_launch("nrf_mlp_pack_weights");
+    return launch_pack(P, packed, as_stream(stream), "nrf_mlp_pack_weights");
 }
 
 static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
@@ -330,11 +326,7 @@ extern "C" int nrf_dnerf_straight_pack_weights(const nrf_net_t *net, const nrf_e
     Planner P{};
     const char *e = plan_net(P, net, emb, net->reserved, true);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_pack_weights: %s", e);
-    for (int i = 0; i < P.pack.nsec; ++i)
-        NRF_REQUIRE(P.pack.sec[i].src || P.pack.sec[i].kind == 4,
-                    "nrf_dnerf_straight_pack_weights: a parameter pointer of the net is null (section %d)", i);
-    hipLaunchKernelGGL(pack_kernel, dim3(64, P.pack.nsec), dim3(256), 0, as_stream(stream), P.pack, packed);
-    return check_launch("nrf_dnerf_straight_pack_weights");
+    return launch_pack(P, packed, as_stream(stream), "nrf_dnerf_straight_pack_weights");
 }
 
 extern "C" int nrf_dnerf_straight_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,

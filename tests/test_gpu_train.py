@@ -316,3 +316,70 @@ def test_query_point_gradients(train_precision, views, W, D, skips, n, ppr):
     if views:
         with pytest.raises(NotImplementedError, match="view directions"):
             net.query_points(pts.detach(), dirs.clone().requires_grad_(True), ppr, L, Lv)
+
+
+@pytest.mark.parametrize("train_precision,W", [("fp32", 64), ("fp32", 256), ("bf16x3", 128)])
+def test_deep_net_with_several_skips(train_precision, W):
+    """D = 16 with three skip layers (the deepest net the kernels take; network.py:29-53): 19 weight-gradient GEMMs and more
+    slab reductions than one batched launch holds, so the backward flushes its queues mid-pass.  Parameter gradients against
+    the same module composed from torch ops in float64."""
+    from nerf_amd.network import NeRF
+    from nerf_amd.positional_encoding import get_embedder
+    torch.manual_seed(5)
+    kw = dict(D=16, W=W, input_ch=63, input_ch_views=27, output_ch=4, skips=[2, 7, 12], use_viewdirs=True)
+    net = NeRF(**kw).cuda()
+    net.train_precision = train_precision
+    rs = np.random.RandomState(9)
+    n, ppr = 40 * 33, 33
+    pts = dev(rs.uniform(-1, 1, (n, 3)).astype(np.float32))
+    dirs = dev(rs.normal(size=(n // ppr, 3)).astype(np.float32))
+    g = dev(rs.normal(size=(n, 4)).astype(np.float32))
+    raw = net.query_points(pts, dirs, ppr, 10, 4)
+    (raw * g).sum().backward()
+    net64 = NeRF(**kw)
+    net64.load_state_dict(net.state_dict())
+    net64 = net64.cuda().double()
+
+    def emb(x, Lx):
+        return torch.cat([x] + [f(x * 2.0 ** j) for j in range(Lx) for f in (torch.sin, torch.cos)], -1)
+    ref = net64._forward_autograd(torch.cat([emb(pts.double(), 10), emb(dirs.double().repeat_interleave(ppr, 0), 4)], -1))
+    assert float((raw.detach().double() - ref.detach()).abs().max()) <= 5e-5 * float(ref.detach().abs().max())
+    (ref * g.double()).sum().backward()
+    worst = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), net64.named_parameters()):
+        e = float((p.grad.double() - q.grad).norm()) / max(float(q.grad.norm()), 1e-30)
+        worst = max(worst, e)
+        assert e <= (2e-4 if train_precision == "fp32" else 1e-2), (k, e)
+    print(f"D=16 W={W} {train_precision}: worst relative gradient error {worst:.2e}")
+
+
+def test_deepest_supported_nets_inference():
+    """D = 16 (the documented maximum) through the other kernels: bf16 / bf16x3 queries against the f32 kernel, the LayerNorm
+    instantiation (115 packed sections: more than one pack launch holds) against its torch composition."""
+    from nerf_amd import vanilla_dynamic as vd
+    from nerf_amd.network import NeRF
+    from nerf_amd.positional_encoding import get_embedder
+    torch.manual_seed(6)
+    rs = np.random.RandomState(10)
+    n, ppr = 64 * 20, 20
+    pts = dev(rs.uniform(-1, 1, (n, 3)).astype(np.float32))
+    dirs = dev(rs.normal(size=(n // ppr, 3)).astype(np.float32))
+    net = NeRF(D=16, W=128, input_ch=63, input_ch_views=27, skips=[3, 9], use_viewdirs=True).cuda()
+    with torch.no_grad():
+        ref = net.query_points(pts, dirs, ppr, 10, 4)
+        net.precision = "bf16x3"
+        x3 = net.query_points(pts, dirs, ppr, 10, 4)
+        net.precision = "bf16"
+        bf = net.query_points(pts, dirs, ppr, 10, 4)
+    scale = float(ref.abs().max())
+    assert float((x3 - ref).abs().max()) <= 5e-5 * scale
+    assert float((bf - ref).abs().max()) <= 3e-2 * scale
+    e, _ = get_embedder(10, 0)
+    ev, _ = get_embedder(4, 0)
+    ln = vd.NeRF(D=16, W=256, input_ch=63, input_ch_views=27, skips=[4, 8, 12], use_viewdirs=True, use_layernorm=True).cuda()
+    with torch.no_grad():
+        x = torch.cat([e(pts), ev(dirs.repeat_interleave(ppr, 0))], -1)
+        a, _ = ln(x)
+        assert ln._packed_cache, "the fused LayerNorm kernel did not run"
+        b = ln._forward_layernorm(x)
+    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
