@@ -98,3 +98,78 @@ def test_non_finite_rows_still_fill_every_merged_slot():
     assert not bool((merged == 12345.0).any())
     for r in (0, 2, 5):
         assert torch.equal(merged[r], ref[r])
+
+
+# ------------------------------------------------------------------ the documented maxima (supported ranges)
+def test_sample_and_composite_at_their_maximum_sizes():
+    """N_samples = 257 coarse + 767 fine = 1024 merged samples (the resampler's and the compositor backward's limit), and
+    one past it refused: sample_pdf + merge against the oracle bit-for-bit, the compositor against torch autograd."""
+    rng = np.random.RandomState(12)
+    N, Nc, Nf = 5, 257, 767
+    rays = dev(fx.blender_rays(N, 3)[:, :8])
+    z = dev(np.sort(rng.uniform(2, 6, (N, Nc)).astype(np.float32), -1))
+    w = dev((rng.uniform(0, 1, (N, Nc)).astype(np.float32)) ** 4)
+    u = dev(rng.uniform(0, 1, (N, Nf)).astype(np.float32))
+    import oracle.oracle as orc
+    from nerf_amd import ops
+    host = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    zs, zm, sd = ops.sample_fine(z, w, Nf, u)
+    zs_o, zm_o, sd_o = orc.sample_fine(host(z), host(w), Nf, u=host(u))
+    assert np.array_equal(host(zs), zs_o) and np.array_equal(host(zm), zm_o)
+    np.testing.assert_allclose(host(sd), sd_o, rtol=1e-6)
+    with pytest.raises(RuntimeError):
+        ops.sample_fine(z, w, Nf + 1, None)
+    S = 1024
+    raw = dev(rng.normal(size=(N, S, 4)).astype(np.float32)).requires_grad_(True)
+    from nerf_amd.render import raw2outputs
+    rgb, disp, acc, weights, depth = raw2outputs(raw, zm, rays[:, 3:6], 0.0, True)
+    (rgb.sum() + acc.sum() + (weights * weights).sum()).backward()
+    r64 = raw.detach().double().requires_grad_(True)
+    d = torch.cat([zm[:, 1:] - zm[:, :-1], torch.full_like(zm[:, :1], 1e10)], -1).double() * rays[:, 3:6].double().norm(dim=-1, keepdim=True)
+    al = 1 - torch.exp(-torch.relu(r64[..., 3]) * d)
+    T = torch.cumprod(torch.cat([torch.ones_like(al[:, :1]), 1 - al + 1e-10], -1), -1)[:, :-1]
+    w64 = al * T
+    rgb64 = (w64[..., None] * torch.sigmoid(r64[..., :3])).sum(-2)
+    acc64 = w64.sum(-1)
+    rgb64 = rgb64 + (1 - acc64[..., None])
+    (rgb64.sum() + acc64.sum() + (w64 * w64).sum()).backward()
+    assert float((raw.grad.double() - r64.grad).abs().max()) <= 2e-5 * float(r64.grad.abs().max())
+
+
+def test_widest_heads_and_embedders():
+    """output_ch = 8 without view directions, multires = 10 / multires_views = 4 (the encoders' maxima), embedded rows of
+    64 + 32 channels: the fused query (forward, and parameter gradients) against the oracle / the torch composition."""
+    from nerf_amd.network import NeRF
+    torch.manual_seed(13)
+    rng = np.random.RandomState(13)
+    n = 3 * 37
+    pts = dev(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
+    net = NeRF(D=3, W=64, input_ch=63, input_ch_views=0, output_ch=8, skips=[1], use_viewdirs=False).cuda()
+    raw = net.query_points(pts, None, 1, 10, 0)
+    assert raw.shape == (n, 8)
+    g = dev(rng.normal(size=(n, 8)).astype(np.float32))
+    (raw * g).sum().backward()
+    net64 = NeRF(D=3, W=64, input_ch=63, input_ch_views=0, output_ch=8, skips=[1], use_viewdirs=False)
+    net64.load_state_dict(net.state_dict())
+    net64 = net64.cuda().double()
+    x = pts.double()
+    xin = torch.cat([x] + [f(x * 2.0 ** j) for j in range(10) for f in (torch.sin, torch.cos)], -1)
+    ref = net64._forward_autograd(xin)
+    assert float((raw.detach().double() - ref.detach()).abs().max()) <= 2e-5 * float(ref.detach().abs().max())
+    (ref * g.double()).sum().backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), net64.named_parameters()):
+        if q.grad is None:
+            continue
+        assert float((p.grad.double() - q.grad).norm()) <= 2e-4 * float(q.grad.norm()), k
+    with pytest.raises(RuntimeError):          # one past the head's width
+        NeRF(D=3, W=64, input_ch=63, input_ch_views=0, output_ch=9, skips=[1], use_viewdirs=False).cuda().query_points(
+            pts, None, 1, 10, 0)
+    # already-embedded rows at the widest the kernel takes: 64 position + 32 direction channels
+    wide = NeRF(D=2, W=128, input_ch=64, input_ch_views=32, skips=[0], use_viewdirs=True).cuda()
+    rows = dev(rng.normal(size=(n, 96)).astype(np.float32))
+    with torch.no_grad():
+        a = wide(rows)
+        b = wide._forward_autograd(rows)
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    with pytest.raises(RuntimeError):
+        NeRF(D=2, W=128, input_ch=66, input_ch_views=32, skips=[0], use_viewdirs=True).cuda()(dev(rng.normal(size=(4, 98))))
