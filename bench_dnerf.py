@@ -116,6 +116,52 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
     return out if rank == 0 else None
 
 
+STRAIGHT_MAC = 84 * 256 + 6 * 256 * 256 + (256 + 84) * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3      # 604 160
+
+
+def run_dnerf_straight(args, torch, device, steps=2, warmup=1):
+    """One 800x800 D-NeRF view with network_type='straightforward' (eight of the reference's sixteen shipped D-NeRF configs;
+    create_dnerf builds a coarse and a fine DNeRF_Straightforward, vanilla_dynamic/model.py:93-99): cat[gamma(x), gamma(t)] ->
+    NeRF-shaped MLP on the fused f32 kernel, 64 + 128 samples.  Single GPU; returns the summary dict."""
+    import nerf_fixtures as fx
+    import nerf_amd.vanilla_dynamic as vd
+    from bench import PEAK_F32_MFMA_TFLOPS
+
+    embed_fn, _ = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = vd.get_time_embedder(10)
+    nets = []
+    for seed in (61, 62):
+        m = vd.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=5, skips=[4],
+                                     use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_straightforward_state(seed).items()}, strict=True)
+        nets.append(m.to(device))
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536,  # noqa: E731
+                                                  network_type='straightforward')
+    kw = dict(network_fn=nets[0], network_fine=nets[1], network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True, network_type='straightforward')
+    H = W = args.size
+    K, _ = fx.intrinsics(H, W)
+
+    def step(i):
+        c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
+        with torch.no_grad():
+            return vd.render_dnerf(H, W, K, 0.1 + 0.08 * i, chunk=32768, c2w=c2w, near=2., far=6., **kw)[0]
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = H * W * 256 * 2 * STRAIGHT_MAC / dt / 1e12
+    return {"value": H * W / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
+            "roofline_frac": tf / PEAK_F32_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+            "workload": f"D-NeRF {H}x{W} view, network_type='straightforward' (coarse + fine DNeRF_Straightforward D=8 W=256), "
+                        "64+128 samples, fp32; FLOP/s over the whole frame's wall time (1.208 MFLOP/point)"}
+
+
 # fwd + bwd of the chain per point: both nets' forward, weight and activation gradients, minus the input-side
 # activation gradients that nothing consumes (time net: gamma(x), gamma(t) of layer 0 and the skip slice; canonical
 # net: the view slice) -- d/d(gamma(x')) of the canonical net IS consumed (it drives the time net).

@@ -152,12 +152,38 @@ class NeRF(nn.Module):
     def _params_in_order(self):
         return [p for _, p in self.named_parameters()]
 
+    # ------------------------------------------------------------------ what the fused kernels take
+    def kernel_shape_reason(self, embedded_rows=False):
+        """None when the fused kernels are built for this architecture, else the reason (supported ranges).
+        The reference has no such limits: architectures outside them run the same arithmetic as a GPU torch composition
+        (forward() on embedded rows, which is also what render.run_network's generic route calls), announced once."""
+        if self.W not in (64, 128, 256):
+            return f"W = {self.W} (the fused kernels are built for W = 64, 128, 256)"
+        if self.D > 16:
+            return f"D = {self.D} (the fused kernels take D <= 16)"
+        if not self.use_viewdirs and self.output_ch > 8:
+            return f"output_ch = {self.output_ch} (the fused head writes <= 8 channels)"
+        if embedded_rows and (not 1 <= self.input_ch <= 64 or self.input_ch_views > 32):
+            return (f"{self.input_ch} + {self.input_ch_views} embedded channels (the fused kernels read <= 64 position and "
+                    "<= 32 direction channels)")
+        return None
+
+    def _composed(self, x2, reason):
+        if not getattr(self, "_warned_composed", False):
+            import warnings
+            warnings.warn(f"nerf_amd: {reason}: this network runs as a GPU torch composition, not on the fused HIP kernels")
+            self._warned_composed = True
+        return self._forward_autograd(x2)
+
     # ------------------------------------------------------------------ queries
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("nerf_amd.NeRF.forward: input is on the CPU; nerf_amd has no CPU path")
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
+        reason = self.kernel_shape_reason(embedded_rows=True)
+        if reason is not None:
+            return self._composed(x2, reason).reshape(*lead, -1)
         if torch.is_grad_enabled() and x2.requires_grad:
             return self._forward_autograd(x2).reshape(*lead, -1)
         out = _QueryFunction.apply(self, (1, 0, 0), x2, None, 1, self._need_grad(x2), *self._params_in_order())

@@ -35,6 +35,8 @@ def batchify(fn, chunk):
 def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
     if not isinstance(fn, NeRF) or not isinstance(embed_fn, _EmbedFn) or not embed_fn.fusable:
         return False
+    if fn.kernel_shape_reason() is not None:      # e.g. --netwidth 96: the generic route below, fn composes GPU torch ops
+        return False
     if embed_fn.out_dim != fn.input_ch or embed_fn.multires > 10:
         return False
     if fn.use_viewdirs:

@@ -19,7 +19,7 @@ from ..rays import get_rays  # noqa: F401  (same arithmetic as render.py:353-365
 from ..render import _FrameDrain, _write_png, raw2outputs  # noqa: F401
 from ..sampling import sample_pdf  # noqa: F401
 from ..utils import DEBUG, to8b
-from .network import DNeRF_Deformation
+from .network import DNeRF_Deformation, DNeRF_Straightforward
 
 
 def batchify(fn, chunk, is_dynamic=True):
@@ -36,7 +36,7 @@ def batchify(fn, chunk, is_dynamic=True):
 
 def _fusable(fn, embed_fn, embeddirs_fn, embed_time_fn, viewdirs):
     if not isinstance(fn, DNeRF_Deformation) or not fn.use_viewdirs or viewdirs is None \
-            or (fn.use_layernorm and fn._training_call()):
+            or (fn.use_layernorm and fn._training_call()) or fn.kernel_shape_reason() is not None:
         return False
     for e, ch, lmax in ((embed_fn, fn.input_ch, 10), (embeddirs_fn, fn.input_ch_views, 4),
                         (embed_time_fn, fn.input_ch_time, 10)):
@@ -65,6 +65,26 @@ def run_network_dnerf(inputs, viewdirs, times, fn, embed_fn, embeddirs_fn, embed
                                   embeddirs_fn.multires, embed_time_fn.multires)
         return raw.reshape(B, N, raw.shape[-1]), dx.reshape(B, N, 3)
 
+    # DNeRF_Straightforward.  At the reference's HEAD this call raises TypeError (the loop below passes pts_raw= / t_raw=,
+    # which that forward(x, ts) does not take: vanilla_dynamic/render.py:112 vs network.py:151) although eight shipped configs
+    # name the network; here it is evaluated as its forward defines -- the one deliberate deviation from the reference's
+    # behaviour on this path.  Inference with the standard embedders: one fused launch on raw points.
+    straight = isinstance(fn, DNeRF_Straightforward)
+    if straight and viewdirs is not None and not torch.is_grad_enabled() and inputs.is_cuda \
+            and all(isinstance(e, _EmbedFn) and e.fusable and e.out_dim == ch and e.multires <= lmax
+                    for e, ch, lmax in ((embed_fn, fn.input_ch, 10), (embeddirs_fn, fn.input_ch_views, 4),
+                                        (embed_time_fn, fn.input_ch_time, 10))) \
+            and fn._kernel_takes():
+        if per_point and times.stride(1) == 0:
+            t_arg, pp = times[:, 0, 0], False
+        elif per_point:
+            t_arg, pp = times.reshape(-1), True
+        else:
+            t_arg, pp = times.reshape(B), False
+        raw = fn.query_points(inputs_flat, viewdirs, t_arg, N, pp, embed_fn.multires, embeddirs_fn.multires,
+                              embed_time_fn.multires)
+        return raw.reshape(B, N, raw.shape[-1]), torch.zeros_like(inputs)
+
     # generic composition: arbitrary networks / embedders, netchunk slices as in the reference
     embedded = embed_fn(inputs_flat)
     if per_point:
@@ -78,8 +98,11 @@ def run_network_dnerf(inputs, viewdirs, times, fn, embed_fn, embeddirs_fn, embed
         embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(dirs, [-1, dirs.shape[-1]]))], -1)
     outs, dxs = [], []
     for i in range(0, embedded.shape[0], netchunk):
-        out, dx = fn(embedded[i:i + netchunk], [embedded_time[i:i + netchunk]] * 2,
-                     pts_raw=inputs_flat[i:i + netchunk], t_raw=t_flat[i:i + netchunk])
+        if straight:
+            out, dx = fn(embedded[i:i + netchunk], [embedded_time[i:i + netchunk]] * 2)
+        else:
+            out, dx = fn(embedded[i:i + netchunk], [embedded_time[i:i + netchunk]] * 2,
+                         pts_raw=inputs_flat[i:i + netchunk], t_raw=t_flat[i:i + netchunk])
         outs.append(out)
         dxs.append(dx)
     outputs = torch.cat(outs, 0)

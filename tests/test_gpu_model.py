@@ -96,3 +96,35 @@ def test_create_dnerf_wiring_and_best_checkpoint(tmp_path):
     tr2, _, start2, _, _ = create_dnerf(_args(tmp_path))
     assert start2 == 70                                                                   # best.tar wins over newer files
     assert torch.equal(tr2['network_fn']._time_out.bias, model._time_out.bias)
+
+
+@pytest.mark.parametrize("kw", [dict(netwidth=96, netwidth_fine=96), dict(multires=12, multires_views=5),
+                                dict(netwidth=96, netwidth_fine=128, use_viewdirs=False)])
+def test_architectures_outside_the_kernels_ranges_still_run(tmp_path, kw):
+    """The reference's parser allows any --netwidth / --multires (model.py:11-34); the fused kernels are built for W in
+    {64, 128, 256} and multires <= 10.  Outside that, create_nerf's networks run the same arithmetic as a GPU torch
+    composition (announced by a warning) instead of refusing: render + a training step work, and a supported net beside
+    them still takes the fused route."""
+    from nerf_amd.model import create_nerf
+    from nerf_amd.render import render
+    from nerf_amd.utils import img2mse
+    train, test, _, _, opt = create_nerf(_args(tmp_path, **kw))
+    K, _ = fx.intrinsics(20, 20)
+    rays = torch.from_numpy(fx.blender_rays(48, 5)[:, :6].astype(np.float32)).cuda()
+    batch = torch.stack([rays[:, :3], rays[:, 3:6]])
+    with pytest.warns(UserWarning, match="GPU torch composition"):
+        rgb, disp, acc, extras = render(20, 20, K, chunk=4096, rays=batch, retraw=True, near=2., far=6., **train)
+    loss = img2mse(rgb, torch.rand_like(rgb)) + img2mse(extras["rgb0"], torch.rand_like(rgb))
+    opt.zero_grad()
+    loss.backward()
+    nets = [train["network_fn"], train["network_fine"]]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n in nets for p in n.parameters()
+               if n.use_viewdirs or not any(p is q for q in n.views_linears.parameters()))
+    opt.step()
+    with torch.no_grad():
+        rgb2, _, _, _ = render(20, 20, K, chunk=4096, rays=batch, near=2., far=6., **test)
+    assert torch.isfinite(rgb2).all() and rgb2.shape == (48, 3)
+    fused = [n for n in nets if n.kernel_shape_reason() is None]
+    if "multires" not in kw:
+        assert len(fused) == (1 if kw.get("netwidth_fine") == 128 else 0)
+        assert all(n._packed_cache for n in fused), "a supported net left the fused route"
