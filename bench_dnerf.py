@@ -162,6 +162,67 @@ def run_dnerf_straight(args, torch, device, steps=2, warmup=1):
                         "64+128 samples, fp32; FLOP/s over the whole frame's wall time (1.208 MFLOP/point)"}
 
 
+def run_dnerf_straight_train(args, torch, device, n_rays=1024, steps=10, warmup=3, fused=True):
+    """One training step with network_type='straightforward' (configs/*_straightforward.txt: N_rand 1024, 64+128 samples,
+    coarse + fine DNeRF_Straightforward, grad_clip 1.0): render_dnerf on a ray batch with per-ray times -> mse(rgb) +
+    mse(rgb0) -> backward -> clipped fused Adam.  fused=False: the same step with the networks composed from GPU torch
+    ops (what nerf_amd ran before the training kernels took this network), for the comparison."""
+    import nerf_fixtures as fx
+    import nerf_amd.vanilla_dynamic as vd
+    from bench import PEAK_F32_MFMA_TFLOPS
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.utils import img2mse
+
+    embed_fn, _ = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = vd.get_time_embedder(10)
+    nets = []
+    for seed in (61, 62):
+        m = vd.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=5, skips=[4],
+                                     use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_straightforward_state(seed).items()}, strict=True)
+        if not fused:
+            m._kernel_takes = lambda: False
+        nets.append(m.to(device))
+    opt = FusedAdam([p for m in nets for p in m.parameters()], lr=5e-4, betas=(0.9, 0.999))
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536,  # noqa: E731
+                                                  network_type='straightforward')
+    kw = dict(network_fn=nets[0], network_fine=nets[1], network_query_fn=qfn, N_samples=64, perturb=1., N_importance=128,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True, network_type='straightforward')
+    H = W = 400
+    K, _ = fx.intrinsics(H, W)
+    ro_np, rd_np, target_np = fx.train_batch(n_rays=n_rays * (steps + warmup), H=H, W=W, seed=7)
+    ro_all, rd_all = torch.from_numpy(ro_np).to(device), torch.from_numpy(rd_np).to(device)
+    target_all = torch.from_numpy(target_np).to(device)
+    times_all = torch.rand(n_rays * (steps + warmup), 1, device=device) * 0.9 + 0.05
+
+    def step(i):
+        sl = slice(i * n_rays, (i + 1) * n_rays)
+        rays = torch.stack([ro_all[sl], rd_all[sl]])
+        rgb, disp, acc, extras = vd.render_dnerf(H, W, K, times_all[sl], chunk=32768, rays=rays, near=2., far=6.,
+                                                 retraw=True, **kw)
+        opt.zero_grad()
+        loss = img2mse(rgb, target_all[sl]) + img2mse(extras['rgb0'], target_all[sl])
+        loss.backward()
+        opt.step(max_grad_norm=1.0)          # vanilla_dynamic/train.py:273-274
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    mac = 3 * STRAIGHT_MAC - (84 * 256 + 84 * 256) - 27 * 128      # no input-side activation gradients
+    tf = n_rays * 256 * 2 * mac / dt / 1e12
+    return {"value": n_rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
+            "roofline_frac": tf / PEAK_F32_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+            "workload": f"D-NeRF straightforward training step, {n_rays}-ray batch with per-ray times, 64+128 samples, coarse + "
+                        f"fine DNeRF_Straightforward D=8 W=256, fp32, forward+backward+clipped fused Adam"
+                        + ("" if fused else " -- networks composed from GPU torch ops (comparison)")}
+
+
 # fwd + bwd of the chain per point: both nets' forward, weight and activation gradients, minus the input-side
 # activation gradients that nothing consumes (time net: gamma(x), gamma(t) of layer 0 and the skip slice; canonical
 # net: the view slice) -- d/d(gamma(x')) of the canonical net IS consumed (it drives the time net).

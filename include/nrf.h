@@ -189,6 +189,18 @@ int nrf_dnerf_straight_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, c
                                  const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
                                  int32_t times_per_point, float *raw, void *stream);
 
+/* DNeRF_Straightforward training (vanilla_dynamic/network.py:151-196 under autograd; the reference trains this network
+ * with loss.backward(), vanilla_dynamic/train.py:266-277): the forward above on raw points (embed mode 0) that also saves
+ * inputs and activations (acts: nrf_train_acts_floats), and the parameter gradients from that workspace (gbuf / slab:
+ * nrf_train_grads_floats / nrf_train_slab_floats; `grads` as in nrf_query_bwd, pts_w[l] with the widths of this network:
+ * [W, input_ch + input_ch_time] for layer 0, [W, input_ch + input_ch_time + W] for the layer after a skip). */
+int nrf_dnerf_straight_fwd_train(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                                 const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                 int32_t times_per_point, float *raw, float *acts, void *stream);
+int nrf_dnerf_straight_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                           const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                           void *stream);
+
 /* ---- bf16 MFMA variant of the network query (BASELINE north star: "optional bf16 variant"; no counterpart in the
  * reference, which is fp32 only).  Same arguments and results as nrf_query_fwd with embed mode 0, computed with
  * bf16 weights / activations and f32 accumulation (v_mfma_f32_32x32x16_bf16); tolerance 1e-2 on rendered values.

@@ -87,6 +87,10 @@ _SIGS = {
     "nrf_dnerf_straight_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_dnerf_straight_query_fwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, C.c_int64, C.c_int32,
                                                C.c_int32, vp, vp]),
+    "nrf_dnerf_straight_fwd_train": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, C.c_int64, C.c_int32,
+                                               C.c_int32, vp, vp, vp]),
+    "nrf_dnerf_straight_bwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
+                                         C.POINTER(NrfNet), vp]),
     "nrf_gen_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int32, vp,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float,
                                C.c_float, vp, vp]),

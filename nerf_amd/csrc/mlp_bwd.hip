@@ -728,12 +728,12 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                           const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256,
-                          bool x3 = false, const void *packed_bwd_x3 = nullptr) {
+                          bool x3 = false, const void *packed_bwd_x3 = nullptr, bool straight = false) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
     Planner P{};
-    const char *e = plan_net(P, net, emb, time_ch);
+    const char *e = plan_net(P, net, emb, time_ch, straight);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: %s", e);
     if (P.plan.layernorm) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: LayerNorm nets have no fused backward");
     if (n_points == 0) return NRF_OK;
@@ -788,20 +788,26 @@ dgrad_done:
         NRF_REQUIRE(grads->pts_w[l] && grads->pts_b[l], "nrf_query_bwd: grads->pts_w/pts_b[%d] is null", l);
         const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * W;
         bool skip = l > 0 && ((net->skips_mask >> (l - 1)) & 1);
-        int ld = l == 0 ? ic + time_ch : (W + (skip ? ic : 0));
+        const int skip_ch = ic + (straight ? time_ch : 0);     // a straightforward net's skip reads cat[gamma(x), gamma(t), h]
+        int ld = l == 0 ? ic + time_ch : (W + (skip ? skip_ch : 0));
         Bwd::Dst dst{0, W, grads->pts_w[l], grads->pts_b[l]};
+        const Bwd::XPart Tin{tl.a_tin, 2 * kKsT, 1, pl.t_type, pl.t_param, kKsT, 0, ic};   // 24 k-space channels of gamma(t)
         Bwd::XPart parts[2];
         int np = 0;
         if (l == 0) {
             parts[np++] = Xin;
-            if (time_ch)   // columns fed by gamma(t) (vanilla_dynamic/network.py:296): 24 k-space channels
-                parts[np++] = Bwd::XPart{tl.a_tin, 2 * kKsT, 1, pl.t_type, pl.t_param, kKsT, 0, ic};
+            if (time_ch) parts[np++] = Tin;   // columns fed by gamma(t) (vanilla_dynamic/network.py:296, :176)
         } else {
-            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * 32 * W, W, nt, BLK_HIDDEN, 0, 0, W, skip ? ic : 0};
+            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * 32 * W, W, nt, BLK_HIDDEN, 0, 0, W, skip ? skip_ch : 0};
             if (skip) parts[np++] = Xin;   // network.py:52-53: cat[input_pts, h]
         }
         rc = B.run(gsec, W, nt, parts, np, ld, &dst, 1);
         if (rc) return rc;
+        if (l > 0 && skip && straight) {   // the gamma(t) columns of the skip layer: a GEMM of their own (no bias)
+            Bwd::Dst dt{0, W, grads->pts_w[l], nullptr};
+            rc = B.run(gsec, W, nt, &Tin, 1, ld, &dt, 1);
+            if (rc) return rc;
+        }
     }
     const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * 32 * W;
     const Bwd::XPart Hlast{a_last, W, nt, BLK_HIDDEN, 0, 0, W, 0};
@@ -867,6 +873,16 @@ extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *
                 "nrf_dnerf_time_bwd: not a time-net descriptor");
     return query_bwd_impl(time_net, emb, time_net->input_ch_views, packed_time, g_dx, acts, gbuf, slab, n_points, grads,
                           nullptr, nullptr, stream);
+}
+
+/* DNeRF_Straightforward training: parameter gradients from the workspace nrf_dnerf_straight_fwd_train saved
+ * (net->reserved = input_ch_time; `packed` from nrf_dnerf_straight_pack_weights). */
+extern "C" int nrf_dnerf_straight_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *g_raw,
+                                      const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
+                                      void *stream) {
+    NRF_REQUIRE(net && net->use_viewdirs && net->reserved > 0, "nrf_dnerf_straight_bwd: not a straightforward-net descriptor");
+    return query_bwd_impl(net, emb, net->reserved, packed, g_raw, acts, gbuf, slab, n_points, grads, nullptr, nullptr, stream,
+                          256, false, nullptr, true);
 }
 
 // ------------------------------------------------------------------------------------------------

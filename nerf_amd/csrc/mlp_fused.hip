@@ -192,6 +192,12 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // 512 registers per lane -> one 4-wave workgroup per CU
     if (a.plan.straight) {
+        if constexpr (!EMB) {
+            if (a.acts) {
+                hipLaunchKernelGGL((query_fwd_kernel<NT, false, true, true, true>), dim3(blocks), dim3(256), 0, st, a);
+                return check_launch("nrf_dnerf_straight_fwd_train");
+            }
+        }
         hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
         return check_launch("nrf_dnerf_straight_query_fwd");
     }
@@ -337,4 +343,17 @@ extern "C" int nrf_dnerf_straight_query_fwd(const nrf_net_t *net, const nrf_embe
     NRF_REQUIRE(net->use_viewdirs, "nrf_dnerf_straight_query_fwd: the fused kernel needs use_viewdirs");
     return query_fwd_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, nullptr, stream, times,
                           emb->mode != 0 || times_per_point ? 1 : pts_per_ray, true);
+}
+
+/* The same forward on raw points (embed mode 0), saving inputs and activations for nrf_dnerf_straight_bwd
+ * (workspace size: nrf_train_acts_floats). */
+extern "C" int nrf_dnerf_straight_fwd_train(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const float *pts,
+                                            const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                            int32_t times_per_point, float *raw, float *acts, void *stream) {
+    NRF_REQUIRE(net && emb, "nrf_dnerf_straight_fwd_train: null descriptor");
+    if (n_points != 0) NRF_REQUIRE(times && acts, "nrf_dnerf_straight_fwd_train: times / acts is null");
+    NRF_REQUIRE(net->use_viewdirs && emb->mode == 0,
+                "nrf_dnerf_straight_fwd_train: needs use_viewdirs and raw points (embed mode 0)");
+    return query_fwd_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream, times,
+                          times_per_point ? 1 : pts_per_ray, true);
 }

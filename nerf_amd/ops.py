@@ -453,8 +453,24 @@ class PackedStraightNet(PackedNet):
               "nrf_dnerf_straight_query_fwd")
         return raw
 
-    def query_train(self, *a, **k):
-        raise NotImplementedError("the fused straightforward kernel is inference only; training composes GPU torch ops")
+    def query_train(self, pts, viewdirs, times, pts_per_ray=1, times_per_point=False):
+        """mode 0 -> (raw [P,4], saved workspace) for query_bwd."""
+        if self.emb.mode != 0:
+            raise NotImplementedError("the straightforward training kernels take raw points (embed mode 0)")
+        self.refresh()
+        pts, times, viewdirs = _f32(pts, "pts"), _f32(times, "times"), _f32(viewdirs, "viewdirs")
+        P = pts.shape[0]
+        raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
+        n = _lib.lib().nrf_train_acts_floats(C.byref(self.net), P)
+        acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
+        check(_lib.lib().nrf_dnerf_straight_fwd_train(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                                      _ptr(viewdirs), _ptr(times), P, int(pts_per_ray),
+                                                      int(bool(times_per_point)), _ptr(raw), _ptr(acts), _stream()),
+              "nrf_dnerf_straight_fwd_train")
+        return raw, acts
+
+    def _bwd_fn(self):
+        return _lib.lib().nrf_dnerf_straight_bwd
 
 
 class PackedNetBf16(PackedNet):

@@ -143,6 +143,29 @@ class NeRF(_StaticNeRF):
         return torch.cat([self.rgb_linear(h), alpha], -1)
 
 
+class _StraightFunction(torch.autograd.Function):
+    """raw = DNeRF_Straightforward on raw points; backward = parameter gradients from the HIP backward kernels
+    (nrf_dnerf_straight_fwd_train / nrf_dnerf_straight_bwd)."""
+
+    @staticmethod
+    def forward(ctx, module, pts, viewdirs, times, pts_per_ray, times_per_point, key, *params):
+        packed = module._raw_packed(key)
+        raw, acts = packed.query_train(pts, viewdirs, times, pts_per_ray, times_per_point)
+        ctx.module, ctx.key, ctx.n_points, ctx.versions = module, key, pts.shape[0], packed._versions
+        ctx.save_for_backward(acts)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        (acts,) = ctx.saved_tensors
+        packed = ctx.module._raw_packed(ctx.key)
+        if packed._versions != ctx.versions:
+            raise RuntimeError("nerf_amd: a parameter of this network was modified between the forward and this backward; "
+                               "the packed weights no longer match the saved activations")
+        grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts)
+        return (None,) * 7 + tuple(grads.get(n) for n, _ in ctx.module.named_parameters())
+
+
 class DNeRF_Straightforward(nn.Module):
     """cat[gamma(x), gamma(t)] -> NeRF-shaped MLP (network.py:100-196).  NB: at the reference's HEAD this
     network type cannot be rendered (run_network_dnerf passes pts_raw=/t_raw= which this forward does not
@@ -187,13 +210,23 @@ class DNeRF_Straightforward(nn.Module):
         """Raw points [P,3], per-ray directions [P/pts_per_ray,3], times [P] or [P/pts_per_ray] -> raw [P,4]: the fused f32
         kernel with in-kernel encodings (nrf_dnerf_straight_query_fwd, embed mode 0).  Inference only."""
         key = (multires, multires_views, multires_time)
+        times = times.reshape(-1)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if pts.requires_grad or times.requires_grad or viewdirs.requires_grad:
+                raise NotImplementedError("nerf_amd: the fused straightforward query differentiates w.r.t. the parameters "
+                                          "only; call forward(x, ts) on embedded rows for input gradients")
+            return _StraightFunction.apply(self, pts, viewdirs, times, int(pts_per_ray), bool(times_per_point), key,
+                                           *[p for _, p in self.named_parameters()])
+        return self._raw_packed(key).query(pts, viewdirs, times, pts_per_ray, times_per_point)
+
+    def _raw_packed(self, key):
         if getattr(self, "_packed_raw_key", None) != key or getattr(self, "_packed_raw", None) is None:
             self._packed_raw = ops.PackedStraightNet(dict(self.named_parameters()), self.D, self.W, self.input_ch,
                                                      self.input_ch_views, self.input_ch_time,
-                                                     [s for s in self.skips if s < self.D - 1], mode=0, multires=multires,
-                                                     multires_views=multires_views, multires_time=multires_time)
+                                                     [s for s in self.skips if s < self.D - 1], mode=0, multires=key[0],
+                                                     multires_views=key[1], multires_time=key[2])
             self._packed_raw_key = key
-        return self._packed_raw.query(pts, viewdirs, times.reshape(-1), pts_per_ray, times_per_point)
+        return self._packed_raw
 
     def forward(self, x, ts):
         t_embed = ts[0] if isinstance(ts, (list, tuple)) else ts

@@ -68,9 +68,10 @@ def run_network_dnerf(inputs, viewdirs, times, fn, embed_fn, embeddirs_fn, embed
     # DNeRF_Straightforward.  At the reference's HEAD this call raises TypeError (the loop below passes pts_raw= / t_raw=,
     # which that forward(x, ts) does not take: vanilla_dynamic/render.py:112 vs network.py:151) although eight shipped configs
     # name the network; here it is evaluated as its forward defines -- the one deliberate deviation from the reference's
-    # behaviour on this path.  Inference with the standard embedders: one fused launch on raw points.
+    # behaviour on this path.  With the standard embedders: one fused launch on raw points (training: the fused
+    # forward that saves activations + the HIP backward kernels).
     straight = isinstance(fn, DNeRF_Straightforward)
-    if straight and viewdirs is not None and not torch.is_grad_enabled() and inputs.is_cuda \
+    if straight and viewdirs is not None and inputs.is_cuda and not inputs.requires_grad and not times.requires_grad \
             and all(isinstance(e, _EmbedFn) and e.fusable and e.out_dim == ch and e.multires <= lmax
                     for e, ch, lmax in ((embed_fn, fn.input_ch, 10), (embeddirs_fn, fn.input_ch_views, 4),
                                         (embed_time_fn, fn.input_ch_time, 10))) \

@@ -484,3 +484,51 @@ def test_straightforward_renders_through_run_network_dnerf(d2, dparts):
     with torch.no_grad():
         rgb = vd.render_dnerf(6, 6, K, 0.3, chunk=64, c2w=c2w, near=2., far=6., **kw)[0]
     assert rgb.shape == (6, 6, 3) and torch.isfinite(rgb).all()
+
+
+def test_straightforward_fused_training_vs_reference(d2, dparts):
+    """Training a straightforward net through the render stack's query (run_network_dnerf with gradients enabled): the fused
+    forward that saves activations + the HIP backward (nrf_dnerf_straight_fwd_train / _bwd) against the imported reference's
+    autograd goldens for the same weights, inputs and output weighting (sf_grad_*); then a deeper / narrower net with
+    another skip position and ragged point count against the GPU torch composition in float64."""
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time) = dparts
+    m = vd.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4, skips=[4],
+                                 use_viewdirs=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_straightforward_state(61).items()}, strict=True)
+    m = m.cuda()
+    pts, dirs, tt = dev(d2["ln_pts"]), dev(d2["ln_dirs"]), dev(d2["ln_times"])
+    raw, dx = vd.run_network_dnerf(pts[:, None, :], dirs, tt, m, embed_fn, embeddirs_fn, embed_time,
+                                   network_type='straightforward')
+    assert raw.requires_grad and m._packed_raw is not None, "the fused training path did not run"
+    assert "_StraightFunction" in type(raw.grad_fn.next_functions[0][0]).__name__
+    np.testing.assert_allclose(host(raw[:, 0]), d2["sf_out"], atol=2e-5 * np.abs(d2["sf_out"]).max(), rtol=0)
+    (raw[:, 0] * dev(d2["sf_gw"])).sum().backward()
+    worst = check_grads(m.named_parameters(), d2, "sf_grad_")
+    print(f"straightforward fused training: worst gradient-norm error vs the reference {worst:.2e}")
+    # another shape, per-ray times, several samples per ray, ragged tile
+    m2 = vd.DNeRF_Straightforward(D=5, W=128, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4, skips=[1],
+                                  use_viewdirs=True)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_straightforward_state(62, D=5, W=128, skips=(1,)).items()})
+    m2 = m2.cuda()
+    rs = np.random.RandomState(8)
+    P, tr = dev(rs.uniform(-1, 1, (7, 11, 3))), dev(rs.uniform(0, 1, (7, 1)))
+    g = dev(rs.normal(size=(7, 11, 4)))
+    out, _ = vd.run_network_dnerf(P, dirs[:7], tr, m2, embed_fn, embeddirs_fn, embed_time)
+    (out * g).sum().backward()
+    got = {k: p.grad.clone() for k, p in m2.named_parameters()}
+    m64 = vd.DNeRF_Straightforward(D=5, W=128, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4, skips=[1],
+                                   use_viewdirs=True)
+    m64.load_state_dict(m2.state_dict())
+    m64 = m64.cuda().double()
+
+    def emb(x, L):
+        return torch.cat([x] + [f(x * 2.0 ** j) for j in range(L) for f in (torch.sin, torch.cos)], -1)
+    x = torch.cat([emb(P.double().reshape(-1, 3), 10), emb(dirs[:7].double()[:, None].expand(7, 11, 3).reshape(-1, 3), 4)], -1)
+    te = emb(tr.double()[:, None].expand(7, 11, 1).reshape(-1, 1), 10)
+    m64._kernel_takes = lambda: False
+    ref, _ = m64(x, [te, te])
+    assert float((out.detach().double().reshape(-1, 4) - ref.detach()).abs().max()) <= 2e-5 * float(ref.detach().abs().max())
+    (ref * g.double().reshape(-1, 4)).sum().backward()
+    for k, p in m64.named_parameters():
+        e = float((got[k].double() - p.grad).norm()) / max(float(p.grad.norm()), 1e-30)
+        assert e <= 2e-4, (k, e)
