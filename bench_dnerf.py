@@ -119,7 +119,7 @@ def run_dnerf(args, torch, dist, world, rank, device, emit=True):
 STRAIGHT_MAC = 84 * 256 + 6 * 256 * 256 + (256 + 84) * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3      # 604 160
 
 
-def run_dnerf_straight(args, torch, device, steps=2, warmup=1):
+def run_dnerf_straight(args, torch, device, steps=2, warmup=1, precision="fp32"):
     """One 800x800 D-NeRF view with network_type='straightforward' (eight of the reference's sixteen shipped D-NeRF configs;
     create_dnerf builds a coarse and a fine DNeRF_Straightforward, vanilla_dynamic/model.py:93-99): cat[gamma(x), gamma(t)] ->
     NeRF-shaped MLP on the fused f32 kernel, 64 + 128 samples.  Single GPU; returns the summary dict."""
@@ -135,6 +135,7 @@ def run_dnerf_straight(args, torch, device, steps=2, warmup=1):
         m = vd.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=5, skips=[4],
                                      use_viewdirs=True)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_straightforward_state(seed).items()}, strict=True)
+        m.precision = precision
         nets.append(m.to(device))
     qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536,  # noqa: E731
                                                   network_type='straightforward')
@@ -156,10 +157,13 @@ def run_dnerf_straight(args, torch, device, steps=2, warmup=1):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     tf = H * W * 256 * 2 * STRAIGHT_MAC / dt / 1e12
-    return {"value": H * W / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
-            "roofline_frac": tf / PEAK_F32_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+    from bench import PEAK_BF16_MFMA_TFLOPS
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3
+    return {"value": H * W / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32" if precision == "fp32" else precision,
+            "roofline_frac": tf / peak, "achieved_TFLOPs": tf,
             "workload": f"D-NeRF {H}x{W} view, network_type='straightforward' (coarse + fine DNeRF_Straightforward D=8 W=256), "
-                        "64+128 samples, fp32; FLOP/s over the whole frame's wall time (1.208 MFLOP/point)"}
+                        f"64+128 samples, {precision}; FLOP/s over the whole frame's wall time (1.208 MFLOP/point"
+                        + (")" if precision == "fp32" else ", f32-equivalent, peak = bf16 peak / 3)")}
 
 
 def run_dnerf_straight_train(args, torch, device, n_rays=1024, steps=10, warmup=3, fused=True):

@@ -201,6 +201,15 @@ int nrf_dnerf_straight_bwd(const nrf_net_t *net, const nrf_embed_t *emb, const f
                            const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                            void *stream);
 
+/* The same query on the bf16x3 arithmetic (three bf16 MFMAs per f32 product on hi/residual operands: f32-grade results,
+ * no counterpart in the reference): `packed` of nrf_dnerf_straight_bf16x3_packed_bytes bytes from
+ * nrf_dnerf_straight_bf16x3_pack_weights; raw points only (embed mode 0), W = 128 or 256, one skip layer. */
+int64_t nrf_dnerf_straight_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_dnerf_straight_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
+int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                        const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                        int32_t times_per_point, float *raw, void *stream);
+
 /* ---- bf16 MFMA variant of the network query (BASELINE north star: "optional bf16 variant"; no counterpart in the
  * reference, which is fp32 only).  Same arguments and results as nrf_query_fwd with embed mode 0, computed with
  * bf16 weights / activations and f32 accumulation (v_mfma_f32_32x32x16_bf16); tolerance 1e-2 on rendered values.

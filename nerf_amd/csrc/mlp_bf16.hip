@@ -172,18 +172,26 @@ static const char *bf_check_net(const nrf_net_t *net, const nrf_embed_t *emb, bo
 // Appends one net's layers in the order the kernel consumes them.  time_net: layer 0 reads cat[gamma(x), gamma(t)],
 // the output layer is `out_w` (W -> 3).  Hidden layers carry their bias as a 17th k-step (constant-1 channel);
 // layers fed by an encoded input take it from that input's constant slot; the one-tile heads add it on the VALU.
-static void bf_plan_net(BfPlan &P, const nrf_net_t *net, const nrf_embed_t *emb, bool time_net) {
+// straight (DNeRF_Straightforward, vanilla_dynamic/network.py:100-196; time channels in net->reserved): layer 0 and the skip
+// layers read cat[gamma(x), gamma(t)] (+ h).
+static void bf_plan_net(BfPlan &P, const nrf_net_t *net, const nrf_embed_t *emb, bool time_net, bool straight = false) {
     const int W = net->W, nt = W / 32, ic = net->input_ch, D = net->D;
     const BfBlock X{BFB_PE3, emb->multires, kBfKsX, 0, ic};
     const BfBlock H{BFB_HIDDEN, 0, 2 * nt, 0, W}, Bi{BFB_BIAS, 0, 1, 0, 0};
-    if (time_net)
+    const int tc = straight ? net->reserved : 0;
+    const BfBlock T{BFB_PE1, emb->multires_time, kBfKsT, ic, tc};
+    if (straight)
+        P.add(net->pts_w[0], net->pts_b[0], ic + tc, W, nt, kBfTail0T, X, T);
+    else if (time_net)
         P.add(net->pts_w[0], net->pts_b[0], ic + net->input_ch_views, W, nt, kBfTail0T, X,
               BfBlock{BFB_PE1, emb->multires_time, kBfKsT, ic, net->input_ch_views});
     else
         P.add(net->pts_w[0], net->pts_b[0], ic, W, nt, kBfTail0, X);
     for (int i = 1; i < D; ++i) {
         const bool skip = (net->skips_mask >> (i - 1)) & 1;   // network.py:52-53
-        if (skip)
+        if (skip && straight)
+            P.add(net->pts_w[i], net->pts_b[i], W + ic + tc, W, nt, kBfTail, X, T, BfBlock{BFB_HIDDEN, 0, 2 * nt, ic + tc, W});
+        else if (skip)
             P.add(net->pts_w[i], net->pts_b[i], W + ic, W, nt, kBfTail, X, BfBlock{BFB_HIDDEN, 0, 2 * nt, ic, W});
         else
             P.add(net->pts_w[i], net->pts_b[i], W, W, nt, kBfTail, H, Bi);
@@ -1206,6 +1214,67 @@ __global__ void __launch_bounds__(256, 1) dnerf_query_fwd_bf16x3_kernel(const Dn
     __builtin_amdgcn_s_barrier();
 }
 
+// DNeRF_Straightforward in bf16x3 (vanilla_dynamic/network.py:151-196): the static query with a gamma(t) block beside
+// gamma(x) at layer 0 and at the skip layer; (rgb, sigma) out, no deformation.
+struct StraightX3Args {
+    Bf16Args b;
+    const float *times;
+    int64_t t_div;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) straight_query_fwd_bf16x3_kernel(const StraightX3Args sa) {
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
+    const Bf16Args &a = sa.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    WStreamX3 st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
+    st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.start();
+    const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
+    const int64_t ntiles = (a.n_points + 127) >> 7;
+    u32x4v one, none;
+    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+    none[0] = 0; none[1] = 0; none[2] = 0; none[3] = 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pp = tile * 128 + st.wave * 32 + n;
+        const int64_t pc = pp < a.n_points ? pp : a.n_points - 1;
+        u32x4v xh[kBfKsX], xl[kBfKsX], th[kBfKsT], tl[kBfKsT], dh[kBfKsD], dl[kBfKsD];
+        {
+            const float *q = a.pts + pc * 3;
+            const float *d = a.viewdirs + (pc / a.pts_per_ray) * 3;
+            fill_pe3_x3<kBfKsD>(dh, dl, d[0], d[1], d[2], h);
+            fill_pe3_x3<kBfKsX>(xh, xl, q[0], q[1], q[2], h);
+            fill_pe1_x3<kBfKsT>(th, tl, sa.times[pc / sa.t_div], h);
+        }
+        auto inh = [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(th[s >= kBfKsX ? s - kBfKsX : 0]); };
+        auto inl = [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(tl[s >= kBfKsX ? s - kBfKsX : 0]); };
+        constexpr int KI = kBfKsX + kBfKsT;
+        f32x16 acc[NT];
+        u32x4v hh[2 * NT], hl[2 * NT];
+        gemm_layer_x3<NT, KI>(acc, st, inh, inl);                                              // network.py:168-172
+        pack_acts_x3<NT>(hh, hl, acc, true);
+        for (int l = 1; l < a.n_trunk; ++l) {
+            if ((a.skip_in_mask >> l) & 1)                                                     // network.py:176-177
+                gemm_layer_x3<NT, KI + 2 * NT>(
+                    acc, st, [&](int s) { return s < KI ? inh(s < KI ? s : 0) : as_bf(hh[s >= KI ? s - KI : 0]); },
+                    [&](int s) { return s < KI ? inl(s < KI ? s : 0) : as_bf(hl[s >= KI ? s - KI : 0]); });
+            else
+                gemm_layer_x3<NT, 2 * NT + 1, true>(
+                    acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
+                    [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });
+            pack_acts_x3<NT>(hh, hl, acc, true);
+        }
+        bf_views_head_x3<NT>(acc, hh, hl, dh, dl, one, none, st, hb, pp, a.n_points, h, a.raw);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -1501,3 +1570,70 @@ int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan 
 #ifdef NRF_BF16_PROFILE
 extern "C" int nrf_bf16_profile_set(unsigned long long *device_counters) { nrf::g_prof_host_ptr = device_counters; return 0; }
 #endif
+
+/* DNeRF_Straightforward on the bf16x3 arithmetic (net->reserved = input_ch_time; raw points, embed mode 0). */
+static const char *bf_check_straight(const nrf_net_t *net, const nrf_embed_t *emb) {
+    if (!net->use_viewdirs) return "the fused straightforward kernels need use_viewdirs";
+    if (const char *e = bf_check_net(net, emb, false)) return e;
+    if (emb->multires_time < 0 || emb->multires_time > 10 || net->reserved != 1 + 2 * emb->multires_time)
+        return "time channels (net->reserved) must equal 1 + 2*multires_time with multires_time <= 10";
+    if (__builtin_popcount((unsigned)net->skips_mask & ((1u << (net->D - 1)) - 1u)) > 1)
+        return "the fused straightforward kernel takes one skip layer";
+    if ((net->skips_mask >> (net->D - 1)) & 1) return "a skip at the last trunk layer is not supported (nor by the reference)";
+    return nullptr;
+}
+
+extern "C" int64_t nrf_dnerf_straight_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+    if (!net || !emb) return -1;
+    if (const char *e = bf_check_straight(net, emb)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_bf16x3_packed_bytes: %s", e); return -1; }
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net(P, net, emb, false, true);
+    return bf_total_bytes(P);
+}
+
+extern "C" int nrf_dnerf_straight_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    NRF_REQUIRE(net && emb && packed, "nrf_dnerf_straight_bf16x3_pack_weights: null pointer");
+    if (const char *e = bf_check_straight(net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_bf16x3_pack_weights: %s", e);
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net(P, net, emb, false, true);
+    return bf_pack(P, packed, as_stream(stream));
+}
+
+extern "C" int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed,
+                                                   const float *pts, const float *viewdirs, const float *times,
+                                                   int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, float *raw,
+                                                   void *stream) {
+    const char *who = "nrf_dnerf_straight_query_fwd_bf16x3";
+    NRF_REQUIRE(net && emb, "%s: null descriptor", who);
+    if (n_points != 0) NRF_REQUIRE(packed && pts && viewdirs && times && raw, "%s: null pointer", who);
+    NRF_REQUIRE(n_points >= 0, "%s: negative n_points", who);
+    if (const char *e = bf_check_straight(net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e);
+    NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0,
+                "%s: packed and raw must be 16-byte aligned", who);
+    NRF_REQUIRE(pts_per_ray >= 1 && n_points % pts_per_ray == 0, "%s: n_points (%lld) must be a multiple of pts_per_ray (%d)",
+                who, (long long)n_points, pts_per_ray);
+    if (n_points == 0) return NRF_OK;
+    BfPlan P;
+    P.split = 1;
+    bf_plan_net(P, net, emb, false, true);
+    StraightX3Args sa{};
+    Bf16Args &a = sa.b;
+    a.stream = (const char *)packed; a.stream_bytes = P.bytes;
+    a.pts = pts; a.viewdirs = viewdirs; a.raw = raw; a.n_points = n_points;
+    a.pts_per_ray = pts_per_ray;
+    a.n_trunk = net->D;
+    a.skip_in_mask = 0;
+    for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
+    a.use_viewdirs = 1; a.output_ch = 4;
+    sa.times = times; sa.t_div = times_per_point ? 1 : pts_per_ray;
+    const int64_t ntiles = (n_points + 127) / 128;
+    const int blocks = (int)(ntiles < 256 ? ntiles : 256);
+    hipStream_t st = as_stream(stream);
+    switch (net->W / 32) {
+        case 8: hipLaunchKernelGGL((straight_query_fwd_bf16x3_kernel<8>), dim3(blocks), dim3(256), 0, st, sa); break;
+        case 4: hipLaunchKernelGGL((straight_query_fwd_bf16x3_kernel<4>), dim3(blocks), dim3(256), 0, st, sa); break;
+    }
+    return check_launch(who);
+}

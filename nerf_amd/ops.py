@@ -473,6 +473,51 @@ class PackedStraightNet(PackedNet):
         return _lib.lib().nrf_dnerf_straight_bwd
 
 
+class PackedStraightNetBf16x3(PackedStraightNet):
+    """hi/residual bf16 weight stream of a DNeRF_Straightforward for nrf_dnerf_straight_query_fwd_bf16x3 (raw points)."""
+
+    def __init__(self, params, D, W, input_ch, input_ch_views, input_ch_time, skips, multires, multires_views, multires_time):
+        self.params = params
+        self.net = NrfNet()
+        n = self.net
+        n.D, n.W, n.input_ch, n.input_ch_views, n.output_ch, n.use_viewdirs = D, W, input_ch, input_ch_views, 4, 1
+        n.reserved = input_ch_time
+        n.skips_mask = sum(1 << int(s) for s in skips)
+        self.emb = NrfEmbed(0, multires, multires_views, multires_time)
+        self.n_bytes = _lib.lib().nrf_dnerf_straight_bf16x3_packed_bytes(C.byref(n), C.byref(self.emb))
+        if self.n_bytes <= 0:
+            raise RuntimeError("nrf_dnerf_straight_bf16x3_packed_bytes: " + _lib.lib().nrf_last_error_string().decode())
+        self.packed = None
+        self._versions = None
+        self.out_ch = 4
+
+    def refresh(self):
+        vers = tuple((v.data_ptr(), v._version) for v in self.params.values())
+        if self.packed is not None and vers == self._versions:
+            return
+        self._fill_pointers()
+        dev = next(iter(self._p.values())).device
+        if self.packed is None or self.packed.device != dev:
+            self.packed = torch.empty((self.n_bytes,), device=dev, dtype=torch.uint8)
+        check(_lib.lib().nrf_dnerf_straight_bf16x3_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
+                                                                _stream()), "nrf_dnerf_straight_bf16x3_pack_weights")
+        self._versions = vers
+
+    def query(self, pts, viewdirs, times, pts_per_ray=1, times_per_point=True):
+        self.refresh()
+        pts, times, viewdirs = _f32(pts, "pts"), _f32(times, "times"), _f32(viewdirs, "viewdirs")
+        P = pts.shape[0]
+        raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
+        check(_lib.lib().nrf_dnerf_straight_query_fwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
+                                                             _ptr(pts), _ptr(viewdirs), _ptr(times), P, int(pts_per_ray),
+                                                             int(bool(times_per_point)), _ptr(raw), _stream()),
+              "nrf_dnerf_straight_query_fwd_bf16x3")
+        return raw
+
+    def query_train(self, *a, **k):
+        raise NotImplementedError("training runs on the exact f32 kernels")
+
+
 class PackedNetBf16(PackedNet):
     """bf16 weight stream of a NeRF module for nrf_query_fwd_bf16 (raw points + in-kernel encoding only)."""
 

@@ -461,6 +461,14 @@ def test_straightforward_renders_through_run_network_dnerf(d2, dparts):
     assert m._packed_raw is not None, "the fused raw-point path did not run"
     assert raw.shape == (320, 1, 4) and dx.shape == (320, 1, 3) and float(dx.abs().max()) == 0.0
     np.testing.assert_allclose(host(raw[:, 0]), ref, atol=2e-5 * np.abs(ref).max(), rtol=0)
+    # bf16x3 arithmetic (three bf16 MFMAs per product): the f32 bar against the reference's golden
+    m.precision = "bf16x3"
+    with torch.no_grad():
+        rx3, _ = vd.run_network_dnerf(pts[:, None, :], dirs, tt, m, embed_fn, embeddirs_fn, embed_time)
+    assert m._packed_x3 is not None, "the bf16x3 path did not run"
+    np.testing.assert_allclose(host(rx3[:, 0]), ref, atol=5e-5 * np.abs(ref).max(), rtol=0)
+    print(f"straightforward bf16x3 vs the reference: {np.abs(host(rx3[:, 0]) - ref).max() / np.abs(ref).max():.2e} of scale")
+    m.precision = "fp32"
     # rays of several samples with per-ray time, and per-point times: fused vs the composed route (grad enabled)
     P = dev(np.random.RandomState(3).uniform(-1, 1, (16, 20, 3)))
     tr = dev(np.random.RandomState(4).uniform(0, 1, (16, 1)))
@@ -468,6 +476,10 @@ def test_straightforward_renders_through_run_network_dnerf(d2, dparts):
         a, _ = vd.run_network_dnerf(P, dirs[:16], tr, m, embed_fn, embeddirs_fn, embed_time)
         a2, _ = vd.run_network_dnerf(P, dirs[:16], tr[:, None, :].expand(16, 20, 1).contiguous(), m, embed_fn, embeddirs_fn,
                                      embed_time)
+        m.precision = "bf16x3"
+        a3, _ = vd.run_network_dnerf(P, dirs[:16], tr, m, embed_fn, embeddirs_fn, embed_time)
+        m.precision = "fp32"
+        assert float((a3 - a).abs().max()) <= 5e-5 * float(a.abs().max())
     b, dxb = vd.run_network_dnerf(P, dirs[:16], tr, m, embed_fn, embeddirs_fn, embed_time)
     assert b.requires_grad and float(dxb.abs().max()) == 0.0
     scale = float(b.detach().abs().max())
