@@ -50,7 +50,8 @@ def main(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for w in ("render", "train", "train_bf16x3", "dnerf", "dnerf_bf16", "dnerf_bf16x3", "render_bf16", "render_bf16x3"):
+    for w in ("render", "train", "train_bf16x3", "dnerf", "dnerf_bf16", "dnerf_bf16x3", "render_bf16", "render_bf16x3",
+              "dnerf_straight"):
         p = os.path.join(src, f"stats_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{rnd}_{w}_kernel_stats.csv"))

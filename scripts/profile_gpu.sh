@@ -54,6 +54,8 @@ for what in "$@"; do
       for c in FETCH_SIZE WRITE_SIZE; do
         timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_render_${P}_$c" -o render_$P -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --precision $P > "$OUT/pmc_render_${P}_$c.log" 2>&1
       done ;;
+    stats_straight)   # network_type='straightforward' (render fp32 / bf16x3, training step) and the LayerNorm kernel
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dnerf_straight" -o dnerf_straight -- python3 $ROOT/scripts/bench_straight.py > "$OUT/dnerf_straight_stats.log" 2>&1 ;;
     stats_dnerf)   # the deformation chain at the three precisions, one kernel-trace run each
       for P in fp32 bf16 bf16x3; do
         W=dnerf_$P; [ $P = fp32 ] && W=dnerf
