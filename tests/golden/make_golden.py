@@ -6,6 +6,7 @@
     python tests/golden/make_golden.py tooling    -> tests/golden/tooling.npz + tests/golden/ref_ckpt_small.tar
     python tests/golden/make_golden.py static2    -> tests/golden/static2.npz  (configs[0] at 100x100; output_ch = 5 nets)
     python tests/golden/make_golden.py dnerf2     -> tests/golden/dnerf2.npz   (well-conditioned D-NeRF, LayerNorm, straightforward)
+    python tests/golden/make_golden.py trajectory -> tests/golden/trajectory.npz (30 steps of the reference's training loop)
 
 The reference (a pure-Python/PyTorch project at /root/reference) cannot travel to the GPU box, so
 its outputs on seeded synthetic inputs are frozen here as data.  Inputs come from
@@ -685,7 +686,76 @@ def gen_dnerf2(out):
     print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
 
 
+TRAJ_STEPS, TRAJ_RAYS = 30, 256
+
+
+def traj_batches():
+    """The fixed schedule of the training-trajectory golden: TRAJ_STEPS batches of TRAJ_RAYS rays (C3-style poses) with a
+    smooth, learnable target colour (a function of the ray direction), shared by the generator and the GPU test."""
+    ro, rd, _ = fx.train_batch(TRAJ_STEPS * TRAJ_RAYS, seed=21)
+    d = rd / np.linalg.norm(rd, axis=-1, keepdims=True)
+    target = (0.5 + 0.5 * np.sin(3.0 * d + np.array([0.0, 1.0, 2.0]))).astype(np.float32)
+    return ro, rd, target
+
+
+def gen_trajectory(out):
+    """The reference's training loop (train.py:226-251: render -> img2mse(rgb) + img2mse(rgb0) -> backward -> Adam ->
+    exponential learning-rate decay) run for TRAJ_STEPS steps on the imported reference, CPU f32: the loss of every step, the
+    PSNR, and the parameters' total movement.  perturb = 0 and raw_noise_std = 0 (no random draws to reproduce)."""
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, REF)
+    import torch
+    import positional_encoding as pe
+    import network
+    import render as rr
+    from utils import img2mse, mse2psnr
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    T = torch.from_numpy
+    e10, _ = pe.get_embedder(10, 0)
+    e4, _ = pe.get_embedder(4, 0)
+    coarse = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(24))
+    fine = _load(torch, network.NeRF(8, 256, 63, 27, 5, [4], True), fx.make_nerf_state(25))
+    w0 = {f"{t}.{k}": p.detach().clone() for t, n in (("coarse", coarse), ("fine", fine)) for k, p in n.named_parameters()}
+    grad_vars = list(coarse.parameters()) + list(fine.parameters())
+    lrate, decay_rate, decay_steps = 5e-4, 0.1, 250 * 1000
+    opt = torch.optim.Adam(params=grad_vars, lr=lrate, betas=(0.9, 0.999))          # model.py:52
+    kw = dict(network_query_fn=lambda i, v, f: rr.run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
+              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0.,
+              ndc=False, lindisp=False)
+    K, _ = fx.intrinsics(400, 400)
+    ro, rd, target = traj_batches()
+    losses, psnrs = [], []
+    for i in range(TRAJ_STEPS):
+        sl = slice(i * TRAJ_RAYS, (i + 1) * TRAJ_RAYS)
+        batch_rays = torch.stack([T(ro[sl]), T(rd[sl])], 0)
+        rgb, disp, acc, extras = rr.render(400, 400, K, chunk=32768, rays=batch_rays, retraw=True, near=2., far=6., **kw)
+        opt.zero_grad()
+        img_loss = img2mse(rgb, T(target[sl]))
+        loss = img_loss + img2mse(extras["rgb0"], T(target[sl]))                    # train.py:232-239
+        loss.backward()
+        opt.step()
+        for g in opt.param_groups:                                                   # train.py:247-251
+            g["lr"] = lrate * (decay_rate ** ((i + 1) / decay_steps))
+        losses.append(loss.item())
+        psnrs.append(mse2psnr(img_loss).item())
+        print(i, losses[-1], psnrs[-1], flush=True)
+    G["losses"], G["psnrs"] = np.array(losses), np.array(psnrs)
+    named = [(f"{t}.{k}", p) for t, n in (("coarse", coarse), ("fine", fine)) for k, p in n.named_parameters()]
+    G["names"] = np.array([k for k, _ in named])
+    G["delta_norms"] = np.array([float((p.detach() - w0[k]).double().norm()) for k, p in named])
+    # the trained nets' image of the first batch: where the whole trajectory ends up
+    with torch.no_grad():
+        rgb, _, acc, extras = rr.render(400, 400, K, chunk=32768, rays=torch.stack([T(ro[:TRAJ_RAYS]), T(rd[:TRAJ_RAYS])], 0),
+                                        retraw=True, near=2., far=6., **kw)
+    G["final_rgb"], G["final_acc"], G["final_rgb0"] = rgb.numpy(), acc.numpy(), extras["rgb0"].numpy()
+    for k, p in named:
+        G[f"final_{k}"] = grad_summary(p)        # [sum, l2, strided subsample] of the trained parameter
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest,
+    {"trajectory": gen_trajectory, "static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest,
      "tooling": gen_tooling, "static2": gen_static2, "dnerf2": gen_dnerf2}[which](os.path.join(HERE, f"{which}.npz"))
