@@ -7,6 +7,7 @@
     python tests/golden/make_golden.py static2    -> tests/golden/static2.npz  (configs[0] at 100x100; output_ch = 5 nets)
     python tests/golden/make_golden.py dnerf2     -> tests/golden/dnerf2.npz   (well-conditioned D-NeRF, LayerNorm, straightforward)
     python tests/golden/make_golden.py trajectory -> tests/golden/trajectory.npz (30 steps of the reference's training loop)
+    python tests/golden/make_golden.py trajectory_dnerf -> tests/golden/trajectory_dnerf.npz (20 steps of the D-NeRF loop)
 
 The reference (a pure-Python/PyTorch project at /root/reference) cannot travel to the GPU box, so
 its outputs on seeded synthetic inputs are frozen here as data.  Inputs come from
@@ -755,7 +756,100 @@ def gen_trajectory(out):
     print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
 
 
+DTRAJ_STEPS, DTRAJ_RAYS, DTRAJ_REG = 20, 256, 1e-2
+
+
+def dtraj_batches():
+    """Schedule of the D-NeRF training-trajectory golden: DTRAJ_STEPS batches of DTRAJ_RAYS rays with per-ray times and a
+    smooth target that moves with time."""
+    ro, rd, _ = fx.train_batch(DTRAJ_STEPS * DTRAJ_RAYS, seed=23)
+    d = rd / np.linalg.norm(rd, axis=-1, keepdims=True)
+    times = np.random.RandomState(24).uniform(0.05, 0.95, (DTRAJ_STEPS * DTRAJ_RAYS, 1)).astype(np.float32)
+    target = (0.5 + 0.5 * np.sin(3.0 * d + 2.0 * times + np.array([0.0, 1.0, 2.0]))).astype(np.float32)
+    return ro, rd, times, target
+
+
+def gen_trajectory_dnerf(out):
+    """vanilla_dynamic/train.py:237-277 for DTRAJ_STEPS steps on the imported reference (CPU): render_dnerf on a ray
+    batch with per-ray times -> mse(rgb) + deform_reg_weight * (mean dx^2 + mean dx0^2) + mse(rgb0) -> backward ->
+    clip_grad_norm_(1.0) -> Adam -> learning-rate decay.  One DNeRF_Deformation for both passes; perturb = 0.
+    Run twice: in float32 (the golden) and, the SAME code, in float64 -- this loop is sensitive (x + dx passes through a
+    frequency-512 encoding, Adam normalises every step), so the distance between the two runs is the reference's own rounding
+    error along the trajectory and bounds what agreement with its float32 run can mean."""
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sys.path.insert(0, os.path.join(REF, "vanilla_dynamic"))
+    import torch
+    import torch.nn as nn
+    import positional_encoding as pe
+    import network
+    import render as rr
+    torch.manual_seed(0)
+    G = {"meta": _meta(torch)}
+    K, _ = fx.intrinsics(400, 400)
+    ro, rd, times, target = dtraj_batches()
+
+    def run(dtype):
+        torch.set_default_dtype(dtype)
+        try:
+            T = lambda a: torch.from_numpy(a).to(dtype)  # noqa: E731
+            embed_fn, _ = pe.get_embedder(10, 0, input_dims=3)
+            embeddirs_fn, _ = pe.get_embedder(4, 0, input_dims=3)
+            embed_time, _ = pe.get_time_embedder(10)
+            model = network.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27,
+                                              input_ch_time=21, output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+            model.load_state_dict({k: T(v) for k, v in fx.make_dnerf_state(33, peaky=False, dx_scale=1.0).items()}, strict=True)
+            model = model.to(dtype)
+            model.embed_fn = embed_fn
+            w0 = {k: p.detach().clone() for k, p in model.named_parameters()}
+            qfn = lambda inputs, viewdirs, tt, fn: rr.run_network_dnerf(  # noqa: E731
+                inputs, viewdirs, tt, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, embed_time_fn=embed_time,
+                netchunk=65536, network_type="deformation")
+            kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+                      white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+            grad_vars = list(model.parameters())
+            lrate, decay_rate, decay_steps = 5e-4, 0.1, 250 * 1000
+            opt = torch.optim.Adam(params=grad_vars, lr=lrate, betas=(0.9, 0.999))
+            losses, gnorms = [], []
+            for i in range(DTRAJ_STEPS):
+                sl = slice(i * DTRAJ_RAYS, (i + 1) * DTRAJ_RAYS)
+                rgb, disp, acc, extras = rr.render_dnerf(400, 400, K, T(times[sl]), chunk=32768,
+                                                         rays=torch.stack([T(ro[sl]), T(rd[sl])], 0), retraw=True, near=2.,
+                                                         far=6., **kw)
+                opt.zero_grad()
+                loss = torch.mean((rgb - T(target[sl])) ** 2)
+                loss = loss + DTRAJ_REG * torch.mean(extras["dx"] ** 2) + DTRAJ_REG * torch.mean(extras["dx0"] ** 2)
+                loss = loss + torch.mean((extras["rgb0"] - T(target[sl])) ** 2)
+                loss.backward()
+                gnorms.append(float(nn.utils.clip_grad_norm_(grad_vars, 1.0)))
+                opt.step()
+                for g in opt.param_groups:
+                    g["lr"] = lrate * (decay_rate ** ((i + 1) / decay_steps))
+                losses.append(loss.item())
+                print(dtype, i, losses[-1], gnorms[-1], flush=True)
+            named = list(model.named_parameters())
+            delta = np.array([float((p.detach() - w0[k]).double().norm()) for k, p in named])
+            with torch.no_grad():
+                sl = slice(0, DTRAJ_RAYS)
+                rgb, _, acc, extras = rr.render_dnerf(400, 400, K, T(times[sl]), chunk=32768,
+                                                      rays=torch.stack([T(ro[sl]), T(rd[sl])], 0), retraw=True, near=2., far=6.,
+                                                      **kw)
+            return (np.array(losses), np.array(gnorms), np.array([k for k, _ in named]), delta, rgb.double().numpy(),
+                    acc.double().numpy())
+        finally:
+            torch.set_default_dtype(torch.float32)
+
+    G["losses"], G["grad_norms"], G["names"], G["delta_norms"], rgb, acc = run(torch.float32)
+    G["final_rgb"], G["final_acc"] = rgb.astype(np.float32), acc.astype(np.float32)
+    G["losses_f64"], G["grad_norms_f64"], _, G["delta_norms_f64"], rgb64, _ = run(torch.float64)
+    G["final_rgb_f64"] = rgb64
+    print("reference f32 vs f64: loss", np.abs(G["losses"] - G["losses_f64"]) / G["losses_f64"])
+    print("   final image", np.abs(G["final_rgb"] - rgb64).max(), "movement",
+          (np.abs(G["delta_norms"] - G["delta_norms_f64"]) / G["delta_norms_f64"]).max())
+    np.savez_compressed(out, **G)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024), len(G), "arrays")
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"trajectory": gen_trajectory, "static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest,
+    {"trajectory_dnerf": gen_trajectory_dnerf, "trajectory": gen_trajectory, "static": gen_static, "dnerf": gen_dnerf, "static_pytest": gen_static_pytest,
      "tooling": gen_tooling, "static2": gen_static2, "dnerf2": gen_dnerf2}[which](os.path.join(HERE, f"{which}.npz"))

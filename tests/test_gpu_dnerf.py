@@ -339,3 +339,75 @@ def test_render_dnerf_row_shards_equal_whole(parts):
                 shards = [parallel.render_rows_dnerf(H, W, K, c2w, tv, r0, n, chunk=64, near=2., far=6., **kw)
                           for r0, n in parallel.row_partition(H, world)]
                 assert torch.equal(torch.cat(shards, 0).reshape(H, W, 5), whole)
+
+
+@pytest.mark.parametrize("train_precision", ["fp32", "bf16x3"])
+def test_dnerf_training_trajectory_vs_reference(parts, train_precision):
+    """Twenty consecutive steps of vanilla_dynamic/train.py:237-277 (render_dnerf with per-ray times -> mse(rgb) +
+    deform_reg_weight * (mean dx^2 + mean dx0^2) + mse(rgb0) -> backward -> clip_grad_norm_(1.0) -> Adam -> lr decay) against
+    the imported reference's own run (CPU f32, tests/golden/trajectory_dnerf.npz): the deformation chain's training kernels,
+    the gradient through extras['dx'], the clip coefficient (active from step 15 on) and the fused Adam in a closed loop."""
+    import importlib.util
+    import os
+    from nerf_amd.optim import FusedAdam
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(here, "golden", "trajectory_dnerf.npz"))
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27, input_ch_time=21,
+                                 output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_dnerf_state(33, peaky=False, dx_scale=1.0).items()},
+                          strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    model.train_precision = train_precision
+    w0 = {k: p.detach().clone() for k, p in model.named_parameters()}
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+    lrate, decay_rate, decay_steps = 5e-4, 0.1, 250 * 1000
+    opt = FusedAdam(list(model.parameters()), lr=lrate, betas=(0.9, 0.999))
+    K, _ = fx.intrinsics(400, 400)
+    ro, rd, times, target = mg.dtraj_batches()
+    R = mg.DTRAJ_RAYS
+    losses, gnorms = [], []
+    for i in range(mg.DTRAJ_STEPS):
+        sl = slice(i * R, (i + 1) * R)
+        rgb, _, _, extras = vd.render_dnerf(400, 400, K, dev(times[sl]), chunk=32768,
+                                            rays=torch.stack([dev(ro[sl]), dev(rd[sl])], 0), retraw=True, near=2., far=6., **kw)
+        opt.zero_grad()
+        loss = torch.mean((rgb - dev(target[sl])) ** 2)
+        loss = loss + mg.DTRAJ_REG * torch.mean(extras["dx"] ** 2) + mg.DTRAJ_REG * torch.mean(extras["dx0"] ** 2)
+        loss = loss + torch.mean((extras["rgb0"] - dev(target[sl])) ** 2)
+        loss.backward()
+        gnorms.append(float(opt.step(max_grad_norm=1.0)))
+        opt.param_groups[0]["lr"] = lrate * (decay_rate ** ((i + 1) / decay_steps))
+        losses.append(loss.item())
+    losses, gnorms = np.array(losses), np.array(gnorms)
+    # This loop is sensitive (x + dx through a frequency-512 encoding, Adam's normalisation): the reference's own float32 and
+    # float64 runs of the same code drift apart along it, to 5e-3 in the loss by step 19 and 1.9e-2 in the trained nets'
+    # image.  That drift (its running maximum: single steps fluctuate) is the yardstick -- held to 3x it against the float32
+    # run, and the first steps, where nothing has been amplified yet, to 1e-5.
+    ref_spread = np.maximum.accumulate(np.abs(gold["losses"] - gold["losses_f64"]) / gold["losses_f64"])
+    rel = np.abs(losses - gold["losses"]) / gold["losses"]
+    rel64 = np.abs(losses - gold["losses_f64"]) / gold["losses_f64"]
+    grel = np.abs(gnorms - gold["grad_norms"]) / gold["grad_norms"]
+    g_spread = np.maximum.accumulate(np.abs(gold["grad_norms"] - gold["grad_norms_f64"]) / gold["grad_norms_f64"])
+    with torch.no_grad():
+        rgbf, _, accf, ex = vd.render_dnerf(400, 400, K, dev(times[:R]), chunk=32768,
+                                            rays=torch.stack([dev(ro[:R]), dev(rd[:R])], 0), retraw=True, near=2., far=6., **kw)
+    d_rgb = float(np.abs(host(rgbf) - gold["final_rgb"]).max())
+    img_spread = float(np.abs(gold["final_rgb"] - gold["final_rgb_f64"]).max())
+    print(f"D-NeRF trajectory ({train_precision}): loss {losses[0]:.4f} -> {losses[-1]:.4f} (reference {gold['losses'][-1]:.4f}, "
+          f"its float64 run {gold['losses_f64'][-1]:.4f}); relative loss difference: first 3 steps {rel[:3].max():.1e}, worst "
+          f"{rel.max():.2e} vs the float32 run, {rel64.max():.2e} vs the float64 run (the reference's own f32-f64 drift: "
+          f"{ref_spread[-1]:.2e}); gradient norm {grel.max():.2e} (drift {g_spread[-1]:.2e}); trained nets' image {d_rgb:.2e} "
+          f"(drift {img_spread:.2e})")
+    first = 3 if train_precision == "fp32" else 2
+    assert rel[:first].max() <= 1e-5, rel[:first]
+    assert np.all(rel <= 3 * ref_spread + 1e-5), (rel, ref_spread)
+    assert np.all(rel64 <= 4 * ref_spread + 1e-5), (rel64, ref_spread)
+    assert np.all(grel <= 3 * g_spread + 1e-5), (grel, g_spread)
+    assert d_rgb <= 2 * img_spread
