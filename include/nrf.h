@@ -233,11 +233,13 @@ int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const 
                        const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
                        void *stream);
 
-/* nrf_dnerf_time_bwd with the weight-gradient GEMMs on the bf16x3 arithmetic (see nrf_query_bwd_bf16x3 below); the
- * activation-gradient chain of the deformation net runs on the exact f32 kernel. */
-int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time, const float *g_dx,
-                              const float *acts, float *gbuf, float *slab, int64_t n_points, const nrf_net_t *grads,
-                              void *stream);
+/* nrf_dnerf_time_bwd with the weight-gradient GEMMs on the bf16x3 arithmetic (see nrf_query_bwd_bf16x3 below) and, when
+ * `packed_bwd_x3` (nrf_mlp_bf16x3_bwd_pack_weights of this descriptor; may be NULL) is given, the deformation net's
+ * activation-gradient chain too: it ends at the net's own parameters, so nothing downstream amplifies the arithmetic's
+ * 1e-5 (the canonical net's chain, which carries d/dx into this one, stays exact f32). */
+int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
+                              const void *packed_bwd_x3, const float *g_dx, const float *acts, float *gbuf, float *slab,
+                              int64_t n_points, const nrf_net_t *grads, void *stream);
 
 /* ---- bf16x3: the same query at f32-grade accuracy on the bf16 matrix pipe (no counterpart in the reference).
  * Every f32 operand is carried as hi = bf16(v), lo = bf16(v - hi); a product is the three MFMAs Wh*xh + Wh*xl + Wl*xh

@@ -81,7 +81,7 @@ _SIGS = {
                                            C.c_int32, vp, vp, vp]),
     "nrf_dnerf_time_bwd": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
                                      C.POINTER(NrfNet), vp]),
-    "nrf_dnerf_time_bwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, C.c_int64,
+    "nrf_dnerf_time_bwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, vp, C.c_int64,
                                             C.POINTER(NrfNet), vp]),
     "nrf_dnerf_straight_packed_floats": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_dnerf_straight_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),

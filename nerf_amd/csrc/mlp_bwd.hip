@@ -753,7 +753,9 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;
     int x3rc = NRF_ERR_UNSUPPORTED;
-    if (x3 && packed_bwd_x3 && !want_gx && time_ch == 0)   // the chain on the bf16 matrix pipe, where a kernel exists
+    // the chain on the bf16 matrix pipe, where a kernel exists: static nets, and the deformation net (its chain ends at its
+    // own parameters: nothing downstream amplifies the 1e-5 of this arithmetic, unlike the canonical net's d/dx)
+    if (x3 && packed_bwd_x3 && !want_gx && !straight)
         x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st);
     if (x3rc != NRF_OK && x3rc != NRF_ERR_UNSUPPORTED) return x3rc;
     if (x3rc == NRF_OK) goto dgrad_done;
@@ -858,12 +860,12 @@ extern "C" int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb
 }
 
 extern "C" int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,
-                                         const float *g_dx, const float *acts, float *gbuf, float *slab, int64_t n_points,
-                                         const nrf_net_t *grads, void *stream) {
+                                         const void *packed_bwd_x3, const float *g_dx, const float *acts, float *gbuf,
+                                         float *slab, int64_t n_points, const nrf_net_t *grads, void *stream) {
     NRF_REQUIRE(time_net && !time_net->use_viewdirs && time_net->input_ch_views > 0,
                 "nrf_dnerf_time_bwd_bf16x3: not a time-net descriptor");
     return query_bwd_impl(time_net, emb, time_net->input_ch_views, packed_time, g_dx, acts, gbuf, slab, n_points, grads,
-                          nullptr, nullptr, stream, 256, true);
+                          nullptr, nullptr, stream, 256, true, packed_bwd_x3);
 }
 
 extern "C" int nrf_dnerf_time_bwd(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,

@@ -308,7 +308,8 @@ class PackedNet:
         else:
             gn.out_w, gn.out_b = g("output_linear.weight"), g("output_linear.bias")
         if x3 and self._bwd_fn() is not lib.nrf_query_bwd:      # deformation net: weight-gradient GEMMs on the bf16 pipe
-            check(lib.nrf_dnerf_time_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(g_raw),
+            check(lib.nrf_dnerf_time_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
+                                                _ptr(self.bwd_x3_stream() if x3 != "wgrad" else None), _ptr(g_raw),
                                                 _ptr(acts), _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()),
                   "nrf_dnerf_time_bwd_bf16x3")
             return grads

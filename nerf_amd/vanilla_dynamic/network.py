@@ -38,7 +38,8 @@ class _DeformFunction(torch.autograd.Function):
         dx = torch.where(skip[:, None], torch.zeros_like(dx), dx)
         x2 = pts + dx
         # train_precision "bf16x3": the canonical net's forward and every weight-gradient GEMM as three bf16 MFMAs per
-        # product; the deformation net's forward and both activation-gradient chains (which carry d/dx) stay exact f32
+        # product, and the deformation net's activation-gradient chain; the deformation net's forward (dx feeds a frequency-512
+        # encoding) and the canonical net's activation-gradient chain (which carries d/dx) stay exact f32
         x3 = module.train_precision == "bf16x3" and module.W in (128, 256) and module.W_deform in (128, 256)
         if module.train_precision not in ("fp32", "bf16x3"):
             raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', not {module.train_precision!r}")
@@ -66,7 +67,8 @@ class _DeformFunction(torch.autograd.Function):
         g_occ, g_x2 = occ.query_bwd(g_raw.contiguous(), ctx.n_points, acts_c, pts=x2, x3="wgrad" if ctx.x3 else False)
         g_dx = g_x2 if g_dx_out is None else g_x2 + g_dx_out
         g_dx = torch.where(skip[:, None], torch.zeros_like(g_dx), g_dx)
-        g_time = tnet.query_bwd(g_dx.contiguous(), ctx.n_points, acts_t, x3="wgrad" if ctx.x3 else False)
+        # the deformation net's own chain ends at its parameters: on the bf16x3 pipe as well
+        g_time = tnet.query_bwd(g_dx.contiguous(), ctx.n_points, acts_t, x3=bool(ctx.x3))
         out = []
         for name, _ in module.named_parameters():
             if name.startswith("_occ."):
