@@ -2,7 +2,9 @@
 """Every pixel of BASELINE configs[1] (800x800, 64+128 samples, D=8 W=256 coarse+fine) against the CPU oracle -- the
 checker of tests/, here run over the WHOLE image (640 000 rays, ~3 min of OpenMP on the GPU box's host cores; the test
 suite samples 1024 pixels).  Well-conditioned nets (fixture seeds 11 / 12); fp32, bf16x3 and bf16 kernels.  Writes
-profiles/<round>_fullsize_parity.json.      python scripts/fullsize_parity.py [round-prefix]"""
+gpurun_out/<round>_fullsize_parity.json (copied to profiles/ by hand).
+    python scripts/fullsize_parity.py [round-prefix] [static,dnerf,fern]
+dnerf: configs[4] at 400x400 (deformation chain, t = 0.5); fern: configs[3], the 1008x756 NDC view."""
 import json
 import os
 import sys
@@ -77,6 +79,114 @@ def run(tag, seeds, peaky):
     ALL[tag] = out
 
 
-run("well_conditioned", (11, 12), False)
-run("sharp", (21, 22), True)
-json.dump(ALL, open(os.path.join(R, "gpurun_out", f"{rnd}_fullsize_parity.json"), "w"), indent=1)
+def compare(tag, prec, got, want, last_sigma, out):
+    rgb, acc, disp = got
+    d = np.abs(rgb - want["rgb_map"]).max(-1)
+    mse = float(np.mean((rgb - want["rgb_map"]) ** 2))
+    dd = np.abs(disp - want["disp_map"])
+    e = {"rgb_max_abs": float(d.max()), "rgb_frac_within_1e-4": float((d <= 1e-4).mean()),
+         "rgb_frac_within_1e-2": float((d <= 1e-2).mean()), "psnr_between_images_dB": float(-10 * np.log10(mse + 1e-30)),
+         "acc_max_abs": float(np.abs(acc - want["acc_map"]).max()),
+         "disp_max_abs_where_finite": float(np.nanmax(np.where(np.isfinite(dd), dd, np.nan))),
+         "rays_with_last_sigma_below_1e-4": int((last_sigma < 1e-4).sum())}
+    stable = last_sigma >= (2e-3 if prec == "bf16" else 1e-4)
+    e["rgb_max_abs_stable_rays"] = float(d[stable].max())
+    out[prec] = e
+    print(tag, prec, json.dumps(e), flush=True)
+
+
+def run_dnerf():
+    """configs[4] at 400x400: DNeRF_Deformation (time net -> dx -> canonical net), t = 0.5, well-conditioned fixture 33."""
+    import nerf_amd.vanilla_dynamic as vd
+    Hd = Wd = 400
+    Kd, _ = fx.intrinsics(Hd, Wd)
+    c2w_d = fx.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    sd = fx.make_dnerf_state(33, peaky=False, dx_scale=1.0)
+    r_all = orc.build_rays(Hd, Wd, Kd, c2w=c2w_d, near=2., far=6., use_viewdirs=True)
+    occ_o, time_o = orc.Net(sd, prefix="_occ."), orc.TimeNet(sd)
+    t0 = time.time()
+    want = {"rgb_map": [], "acc_map": [], "disp_map": []}
+    for i in range(0, r_all.shape[0], 16384):
+        rr_ = r_all[i:i + 16384]
+        tt = np.full((rr_.shape[0], 1), 0.5, np.float32)
+        q = lambda p, v, n, tt=tt: orc.run_network_dnerf(p, v, tt, occ_o, time_o)[0]  # noqa: E731
+        r = orc.render_rays(rr_, occ_o, None, N_samples=64, N_importance=128, white_bkgd=True, query=q)
+        for k in want:
+            want[k].append(r[k])
+        print(f"oracle (dnerf): {i + 16384} rays, {time.time() - t0:.0f} s", flush=True)
+    want = {k: np.concatenate(v) for k, v in want.items()}
+    out = {"workload": "D-NeRF deformation chain, 400x400 view at t = 0.5, 64+128 samples, one model for both passes, fixture 33 "
+                       "(well-conditioned); all 160000 pixels", "oracle_seconds": time.time() - t0}
+    embed_fn, _ = vd.get_embedder(10, 0, input_dims=3)
+    embeddirs_fn, _ = vd.get_embedder(4, 0, input_dims=3)
+    embed_time, _ = vd.get_time_embedder(10)
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27, input_ch_time=21,
+                                 output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
+    kwd = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+               white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+    for prec in ("fp32", "bf16x3", "bf16"):
+        model.precision = prec
+        with torch.no_grad():
+            rgb, disp, acc, ex = vd.render_dnerf(Hd, Wd, Kd, 0.5, chunk=32768, c2w=torch.from_numpy(c2w_d).cuda(), near=2.,
+                                                 far=6., retraw=True, **kwd)
+        got = tuple(t.reshape(-1, *t.shape[2:]).cpu().numpy() for t in (rgb, acc, disp))
+        compare("dnerf_400", prec, got, want, ex["raw"][..., -1, 3].reshape(-1).abs().cpu().numpy(), out)
+    ALL["dnerf_400"] = out
+
+
+def run_fern():
+    """configs[3]: 1008x756 forward-facing NDC view, 64+128 samples, well-conditioned nets 11 / 12, black background."""
+    Hf, Wf = 756, 1008
+    Kf = np.array([[815.0, 0, 0.5 * Wf], [0, 815.0, 0.5 * Hf], [0, 0, 1]], dtype=np.float32)
+    c2w_f = np.eye(4, dtype=np.float32)[:3, :4].copy()
+    c2w_f[0, 3] = 0.04
+    r_all = orc.build_rays(Hf, Wf, Kf, c2w=c2w_f, ndc=True, near=0., far=1., use_viewdirs=True)
+    co, fo = orc.Net(fx.make_nerf_state(11)), orc.Net(fx.make_nerf_state(12))
+    t0 = time.time()
+    want = {"rgb_map": [], "acc_map": [], "disp_map": []}
+    for i in range(0, r_all.shape[0], 32768):
+        r = orc.render_rays(r_all[i:i + 32768], co, fo, N_samples=64, N_importance=128, white_bkgd=False)
+        for k in want:
+            want[k].append(r[k])
+        print(f"oracle (fern): {i + 32768} rays, {time.time() - t0:.0f} s", flush=True)
+    want = {k: np.concatenate(v) for k, v in want.items()}
+    out = {"workload": "LLFF-fern-shaped 1008x756 NDC view, 64+128 samples, D=8 W=256 coarse+fine, fixture seeds 11/12; all "
+                       "762048 pixels", "oracle_seconds": time.time() - t0}
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    nets = []
+    for seed in (11, 12):
+        net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_nerf_state(seed).items()})
+        nets.append(net.cuda())
+    kwf = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
+               network_fine=nets[1], N_samples=64, network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
+               ndc=True, lindisp=False)
+    for prec in ("fp32", "bf16x3", "bf16"):
+        for n in nets:
+            n.precision = prec
+        with torch.no_grad():
+            rgb, disp, acc, ex = render(Hf, Wf, Kf, chunk=32768, c2w=torch.from_numpy(c2w_f).cuda(), near=0., far=1.,
+                                        retraw=True, **kwf)
+        got = tuple(t.reshape(-1, *t.shape[2:]).cpu().numpy() for t in (rgb, acc, disp))
+        compare("fern_ndc", prec, got, want, ex["raw"][..., -1, 3].reshape(-1).abs().cpu().numpy(), out)
+    ALL["fern_ndc"] = out
+
+
+what = sys.argv[2].split(",") if len(sys.argv) > 2 else ["static"]
+path = os.path.join(R, "gpurun_out", f"{rnd}_fullsize_parity.json")
+prev = os.path.join(R, "profiles", f"{rnd}_fullsize_parity.json")
+if os.path.exists(prev):       # keep what an earlier run recorded for the workloads not repeated now
+    ALL.update({k: v for k, v in json.load(open(prev)).items() if k != "workload"})
+if "static" in what:
+    run("well_conditioned", (11, 12), False)
+    run("sharp", (21, 22), True)
+if "dnerf" in what:
+    run_dnerf()
+if "fern" in what:
+    run_fern()
+json.dump(ALL, open(path, "w"), indent=1)
