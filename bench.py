@@ -256,6 +256,7 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
         also[f"dnerf_{prec}"] = brief(bench_dnerf.run_dnerf(a, torch, dist, 1, 0, device, emit=False))
     also["dnerf_straightforward_fp32"] = bench_dnerf.run_dnerf_straight(a, torch, device)
     also["dnerf_straightforward_bf16x3"] = bench_dnerf.run_dnerf_straight(a, torch, device, precision="bf16x3")
+    also["dnerf_straightforward_bf16"] = bench_dnerf.run_dnerf_straight(a, torch, device, precision="bf16")
     also["dnerf_straightforward_train_step"] = bench_dnerf.run_dnerf_straight_train(a, torch, device)
     also["dnerf_train_step"] = bench_dnerf.run_dnerf_train(a, torch, device)
     also["dnerf_train_step_bf16x3"] = bench_dnerf.run_dnerf_train(a, torch, device, train_precision="bf16x3")

@@ -158,12 +158,12 @@ def run_dnerf_straight(args, torch, device, steps=2, warmup=1, precision="fp32")
     dt = (time.perf_counter() - t0) / steps
     tf = H * W * 256 * 2 * STRAIGHT_MAC / dt / 1e12
     from bench import PEAK_BF16_MFMA_TFLOPS
-    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3
+    peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS}[precision]
     return {"value": H * W / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32" if precision == "fp32" else precision,
             "roofline_frac": tf / peak, "achieved_TFLOPs": tf,
             "workload": f"D-NeRF {H}x{W} view, network_type='straightforward' (coarse + fine DNeRF_Straightforward D=8 W=256), "
                         f"64+128 samples, {precision}; FLOP/s over the whole frame's wall time (1.208 MFLOP/point"
-                        + (")" if precision == "fp32" else ", f32-equivalent, peak = bf16 peak / 3)")}
+                        + (", f32-equivalent, peak = bf16 peak / 3)" if precision == "bf16x3" else ")")}
 
 
 def run_dnerf_straight_train(args, torch, device, n_rays=1024, steps=10, warmup=3, fused=True):

@@ -210,6 +210,13 @@ int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t 
                                         const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
                                         int32_t times_per_point, float *raw, void *stream);
 
+/* ... and on plain bf16 MFMAs (the north star's optional bf16 variant, tolerance 1e-2): same arguments and limits. */
+int64_t nrf_dnerf_straight_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
+int nrf_dnerf_straight_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
+int nrf_dnerf_straight_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                      const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                                      int32_t times_per_point, float *raw, void *stream);
+
 /* ---- bf16 MFMA variant of the network query (BASELINE north star: "optional bf16 variant"; no counterpart in the
  * reference, which is fp32 only).  Same arguments and results as nrf_query_fwd with embed mode 0, computed with
  * bf16 weights / activations and f32 accumulation (v_mfma_f32_32x32x16_bf16); tolerance 1e-2 on rendered values.

@@ -95,6 +95,10 @@ _SIGS = {
     "nrf_dnerf_straight_bf16x3_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_dnerf_straight_query_fwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, C.c_int64,
                                                       C.c_int32, C.c_int32, vp, vp]),
+    "nrf_dnerf_straight_bf16_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
+    "nrf_dnerf_straight_bf16_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
+    "nrf_dnerf_straight_query_fwd_bf16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, C.c_int64,
+                                                    C.c_int32, C.c_int32, vp, vp]),
     "nrf_gen_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int32, vp,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float,
                                C.c_float, vp, vp]),

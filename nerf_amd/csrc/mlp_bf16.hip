@@ -1222,6 +1222,60 @@ struct StraightX3Args {
     int64_t t_div;
 };
 
+// The same network on plain bf16 MFMAs (tolerance 1e-2): the structure of query_fwd_bf16_kernel, 64 points per wave.
+template <int NT>
+__global__ void __launch_bounds__(256, 1) straight_query_fwd_bf16_kernel(const StraightX3Args sa) {
+    __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
+    const Bf16Args &a = sa.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    WStream st;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.stream), 0, (int)a.stream_bytes, 0x00020000);
+    st.lds = lds;
+    st.total = (uint32_t)a.stream_bytes;
+    st.lane16 = lane * 16;
+    st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    st.start();
+    const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
+    const int64_t ntiles = (a.n_points + 255) >> 8;
+    u32x4v one;
+    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+    constexpr int KI = kBfKsX + kBfKsT;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t pp[2], pc[2];
+        u32x4v xin[2][kBfKsX], tin[2][kBfKsT], din[2][kBfKsD];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pp[p] = tile * 256 + st.wave * 64 + p * 32 + n;
+            pc[p] = pp[p] < a.n_points ? pp[p] : a.n_points - 1;
+            const float *q = a.pts + pc[p] * 3;
+            const float *d = a.viewdirs + (pc[p] / a.pts_per_ray) * 3;
+            fill_pe3_bf16<kBfKsD>(din[p], d[0], d[1], d[2], h);
+            fill_pe3_bf16<kBfKsX>(xin[p], q[0], q[1], q[2], h);
+            fill_pe1_bf16<kBfKsT>(tin[p], sa.times[pc[p] / sa.t_div], h);
+        }
+        auto in = [&](int p, int s) { return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(tin[p][s >= kBfKsX ? s - kBfKsX : 0]); };
+        f32x16 acc[2][NT];
+        u32x4v hin[2][2 * NT];
+        gemm_layer<NT, KI>(acc, st, in);                                                       // network.py:168-172
+        pack_acts<NT>(hin, acc, true);
+        for (int l = 1; l < a.n_trunk; ++l) {
+            if ((a.skip_in_mask >> l) & 1)                                                     // network.py:176-177
+                gemm_layer<NT, KI + 2 * NT>(acc, st, [&](int p, int s) {
+                    return s < KI ? in(p, s < KI ? s : 0) : as_bf(hin[p][s >= KI ? s - KI : 0]);
+                });
+            else
+                gemm_layer<NT, 2 * NT + 1>(acc, st, [&](int p, int s) {
+                    return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
+                });
+            pack_acts<NT>(hin, acc, true);
+        }
+        bf_views_head<NT>(acc, hin, one, st, hb, din, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, nullptr);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256, 1) straight_query_fwd_bf16x3_kernel(const StraightX3Args sa) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
@@ -1583,29 +1637,27 @@ static const char *bf_check_straight(const nrf_net_t *net, const nrf_embed_t *em
     return nullptr;
 }
 
-extern "C" int64_t nrf_dnerf_straight_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+static int64_t straight_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb, int split, const char *who) {
     if (!net || !emb) return -1;
-    if (const char *e = bf_check_straight(net, emb)) { nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_bf16x3_packed_bytes: %s", e); return -1; }
+    if (const char *e = bf_check_straight(net, emb)) { nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e); return -1; }
     BfPlan P;
-    P.split = 1;
+    P.split = split;
     bf_plan_net(P, net, emb, false, true);
     return bf_total_bytes(P);
 }
 
-extern "C" int nrf_dnerf_straight_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
-    NRF_REQUIRE(net && emb && packed, "nrf_dnerf_straight_bf16x3_pack_weights: null pointer");
-    if (const char *e = bf_check_straight(net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_dnerf_straight_bf16x3_pack_weights: %s", e);
+static int straight_pack(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream, int split, const char *who) {
+    NRF_REQUIRE(net && emb && packed, "%s: null pointer", who);
+    if (const char *e = bf_check_straight(net, emb)) return nrf::fail(NRF_ERR_UNSUPPORTED, "%s: %s", who, e);
     BfPlan P;
-    P.split = 1;
+    P.split = split;
     bf_plan_net(P, net, emb, false, true);
     return bf_pack(P, packed, as_stream(stream));
 }
 
-extern "C" int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed,
-                                                   const float *pts, const float *viewdirs, const float *times,
-                                                   int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, float *raw,
-                                                   void *stream) {
-    const char *who = "nrf_dnerf_straight_query_fwd_bf16x3";
+static int straight_query(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                          const float *viewdirs, const float *times, int64_t n_points, int32_t pts_per_ray,
+                          int32_t times_per_point, float *raw, void *stream, int split, const char *who) {
     NRF_REQUIRE(net && emb, "%s: null descriptor", who);
     if (n_points != 0) NRF_REQUIRE(packed && pts && viewdirs && times && raw, "%s: null pointer", who);
     NRF_REQUIRE(n_points >= 0, "%s: negative n_points", who);
@@ -1616,7 +1668,7 @@ extern "C" int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const n
                 who, (long long)n_points, pts_per_ray);
     if (n_points == 0) return NRF_OK;
     BfPlan P;
-    P.split = 1;
+    P.split = split;
     bf_plan_net(P, net, emb, false, true);
     StraightX3Args sa{};
     Bf16Args &a = sa.b;
@@ -1628,12 +1680,40 @@ extern "C" int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const n
     for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
     a.use_viewdirs = 1; a.output_ch = 4;
     sa.times = times; sa.t_div = times_per_point ? 1 : pts_per_ray;
-    const int64_t ntiles = (n_points + 127) / 128;
+    const int64_t ntiles = split ? (n_points + 127) / 128 : (n_points + 255) / 256;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);
     hipStream_t st = as_stream(stream);
-    switch (net->W / 32) {
-        case 8: hipLaunchKernelGGL((straight_query_fwd_bf16x3_kernel<8>), dim3(blocks), dim3(256), 0, st, sa); break;
-        case 4: hipLaunchKernelGGL((straight_query_fwd_bf16x3_kernel<4>), dim3(blocks), dim3(256), 0, st, sa); break;
+    switch (net->W / 32 + (split ? 100 : 0)) {
+        case 108: hipLaunchKernelGGL((straight_query_fwd_bf16x3_kernel<8>), dim3(blocks), dim3(256), 0, st, sa); break;
+        case 104: hipLaunchKernelGGL((straight_query_fwd_bf16x3_kernel<4>), dim3(blocks), dim3(256), 0, st, sa); break;
+        case 8: hipLaunchKernelGGL((straight_query_fwd_bf16_kernel<8>), dim3(blocks), dim3(256), 0, st, sa); break;
+        case 4: hipLaunchKernelGGL((straight_query_fwd_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, sa); break;
     }
     return check_launch(who);
+}
+
+extern "C" int64_t nrf_dnerf_straight_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+    return straight_packed_bytes(net, emb, 1, "nrf_dnerf_straight_bf16x3_packed_bytes");
+}
+extern "C" int nrf_dnerf_straight_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    return straight_pack(net, emb, packed, stream, 1, "nrf_dnerf_straight_bf16x3_pack_weights");
+}
+extern "C" int nrf_dnerf_straight_query_fwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed,
+                                                   const float *pts, const float *viewdirs, const float *times,
+                                                   int64_t n_points, int32_t pts_per_ray, int32_t times_per_point, float *raw,
+                                                   void *stream) {
+    return straight_query(net, emb, packed, pts, viewdirs, times, n_points, pts_per_ray, times_per_point, raw, stream, 1,
+                          "nrf_dnerf_straight_query_fwd_bf16x3");
+}
+extern "C" int64_t nrf_dnerf_straight_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
+    return straight_packed_bytes(net, emb, 0, "nrf_dnerf_straight_bf16_packed_bytes");
+}
+extern "C" int nrf_dnerf_straight_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    return straight_pack(net, emb, packed, stream, 0, "nrf_dnerf_straight_bf16_pack_weights");
+}
+extern "C" int nrf_dnerf_straight_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed,
+                                                 const float *pts, const float *viewdirs, const float *times, int64_t n_points,
+                                                 int32_t pts_per_ray, int32_t times_per_point, float *raw, void *stream) {
+    return straight_query(net, emb, packed, pts, viewdirs, times, n_points, pts_per_ray, times_per_point, raw, stream, 0,
+                          "nrf_dnerf_straight_query_fwd_bf16");
 }

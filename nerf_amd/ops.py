@@ -475,9 +475,12 @@ class PackedStraightNet(PackedNet):
 
 
 class PackedStraightNetBf16x3(PackedStraightNet):
-    """hi/residual bf16 weight stream of a DNeRF_Straightforward for nrf_dnerf_straight_query_fwd_bf16x3 (raw points)."""
+    """bf16 weight stream of a DNeRF_Straightforward for nrf_dnerf_straight_query_fwd_bf16x3 (kind "bf16x3": hi/residual
+    pairs) or nrf_dnerf_straight_query_fwd_bf16 (kind "bf16"); raw points."""
 
-    def __init__(self, params, D, W, input_ch, input_ch_views, input_ch_time, skips, multires, multires_views, multires_time):
+    def __init__(self, params, D, W, input_ch, input_ch_views, input_ch_time, skips, multires, multires_views, multires_time,
+                 kind="bf16x3"):
+        self.kind = kind
         self.params = params
         self.net = NrfNet()
         n = self.net
@@ -485,9 +488,9 @@ class PackedStraightNetBf16x3(PackedStraightNet):
         n.reserved = input_ch_time
         n.skips_mask = sum(1 << int(s) for s in skips)
         self.emb = NrfEmbed(0, multires, multires_views, multires_time)
-        self.n_bytes = _lib.lib().nrf_dnerf_straight_bf16x3_packed_bytes(C.byref(n), C.byref(self.emb))
+        self.n_bytes = getattr(_lib.lib(), f"nrf_dnerf_straight_{kind}_packed_bytes")(C.byref(n), C.byref(self.emb))
         if self.n_bytes <= 0:
-            raise RuntimeError("nrf_dnerf_straight_bf16x3_packed_bytes: " + _lib.lib().nrf_last_error_string().decode())
+            raise RuntimeError(f"nrf_dnerf_straight_{kind}_packed_bytes: " + _lib.lib().nrf_last_error_string().decode())
         self.packed = None
         self._versions = None
         self.out_ch = 4
@@ -500,8 +503,8 @@ class PackedStraightNetBf16x3(PackedStraightNet):
         dev = next(iter(self._p.values())).device
         if self.packed is None or self.packed.device != dev:
             self.packed = torch.empty((self.n_bytes,), device=dev, dtype=torch.uint8)
-        check(_lib.lib().nrf_dnerf_straight_bf16x3_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
-                                                                _stream()), "nrf_dnerf_straight_bf16x3_pack_weights")
+        check(getattr(_lib.lib(), f"nrf_dnerf_straight_{self.kind}_pack_weights")(
+            C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()), f"nrf_dnerf_straight_{self.kind}_pack_weights")
         self._versions = vers
 
     def query(self, pts, viewdirs, times, pts_per_ray=1, times_per_point=True):
@@ -509,10 +512,9 @@ class PackedStraightNetBf16x3(PackedStraightNet):
         pts, times, viewdirs = _f32(pts, "pts"), _f32(times, "times"), _f32(viewdirs, "viewdirs")
         P = pts.shape[0]
         raw = torch.empty((P, 4), device=pts.device, dtype=torch.float32)
-        check(_lib.lib().nrf_dnerf_straight_query_fwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
-                                                             _ptr(pts), _ptr(viewdirs), _ptr(times), P, int(pts_per_ray),
-                                                             int(bool(times_per_point)), _ptr(raw), _stream()),
-              "nrf_dnerf_straight_query_fwd_bf16x3")
+        check(getattr(_lib.lib(), f"nrf_dnerf_straight_query_fwd_{self.kind}")(
+            C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts), _ptr(viewdirs), _ptr(times), P,
+            int(pts_per_ray), int(bool(times_per_point)), _ptr(raw), _stream()), f"nrf_dnerf_straight_query_fwd_{self.kind}")
         return raw
 
     def query_train(self, *a, **k):

@@ -192,7 +192,8 @@ class DNeRF_Straightforward(nn.Module):
         else:
             self.output_linear = nn.Linear(W, output_ch)
         self._packed = None
-        # "fp32" (the reference's arithmetic) or "bf16x3" (three bf16 MFMAs per product, f32-grade results): inference
+        # "fp32" (the reference's arithmetic), "bf16" (bf16 MFMA, tolerance 1e-2) or "bf16x3" (three bf16 MFMAs per product,
+        # f32-grade results): inference
         # through the render stack's fused query only; training stays exact f32.  Not a constructor argument of the reference
         self.precision = "fp32"
 
@@ -223,15 +224,17 @@ class DNeRF_Straightforward(nn.Module):
                                           "only; call forward(x, ts) on embedded rows for input gradients")
             return _StraightFunction.apply(self, pts, viewdirs, times, int(pts_per_ray), bool(times_per_point), key,
                                            *[p for _, p in self.named_parameters()])
-        if self.precision == "bf16x3":
+        if self.precision in ("bf16", "bf16x3"):
+            key = key + (self.precision,)
             if getattr(self, "_packed_x3_key", None) != key or getattr(self, "_packed_x3", None) is None:
                 self._packed_x3 = ops.PackedStraightNetBf16x3(dict(self.named_parameters()), self.D, self.W, self.input_ch,
                                                               self.input_ch_views, self.input_ch_time,
-                                                              [s for s in self.skips if s < self.D - 1], *key)
+                                                              [s for s in self.skips if s < self.D - 1], *key[:3],
+                                                              kind=self.precision)
                 self._packed_x3_key = key
             return self._packed_x3.query(pts, viewdirs, times, pts_per_ray, times_per_point)
         if self.precision != "fp32":
-            raise ValueError(f"nerf_amd: precision {self.precision!r} is not built for DNeRF_Straightforward (fp32, bf16x3)")
+            raise ValueError(f"nerf_amd: unknown precision {self.precision!r} (fp32, bf16 or bf16x3)")
         return self._raw_packed(key).query(pts, viewdirs, times, pts_per_ray, times_per_point)
 
     def _raw_packed(self, key):

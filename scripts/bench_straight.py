@@ -20,7 +20,7 @@ from nerf_amd import vanilla_dynamic as vd  # noqa: E402
 dev = torch.device("cuda:0")
 a = types.SimpleNamespace(size=int(sys.argv[1]) if len(sys.argv) > 1 else 800)
 out = {}
-for prec in ("fp32", "bf16x3"):
+for prec in ("fp32", "bf16x3", "bf16"):
     out[f"straightforward_render_{prec}"] = bench_dnerf.run_dnerf_straight(a, torch, dev, precision=prec)
 out["straightforward_train_step"] = bench_dnerf.run_dnerf_straight_train(a, torch, dev)
 out["straightforward_train_step_composed"] = bench_dnerf.run_dnerf_straight_train(a, torch, dev, fused=False)

@@ -468,6 +468,11 @@ def test_straightforward_renders_through_run_network_dnerf(d2, dparts):
     assert m._packed_x3 is not None, "the bf16x3 path did not run"
     np.testing.assert_allclose(host(rx3[:, 0]), ref, atol=5e-5 * np.abs(ref).max(), rtol=0)
     print(f"straightforward bf16x3 vs the reference: {np.abs(host(rx3[:, 0]) - ref).max() / np.abs(ref).max():.2e} of scale")
+    m.precision = "bf16"                       # plain bf16 MFMAs: the north star's 1e-2
+    with torch.no_grad():
+        rbf, _ = vd.run_network_dnerf(pts[:, None, :], dirs, tt, m, embed_fn, embeddirs_fn, embed_time)
+    np.testing.assert_allclose(host(rbf[:, 0]), ref, atol=1e-2 * np.abs(ref).max(), rtol=0)
+    print(f"straightforward bf16 vs the reference: {np.abs(host(rbf[:, 0]) - ref).max() / np.abs(ref).max():.2e} of scale")
     m.precision = "fp32"
     # rays of several samples with per-ray time, and per-point times: fused vs the composed route (grad enabled)
     P = dev(np.random.RandomState(3).uniform(-1, 1, (16, 20, 3)))
