@@ -67,6 +67,33 @@ def is_dnerf(sd):
     return any(k.startswith("_occ.") for k in sd)
 
 
+def infer_straight_arch(sd, args=None):
+    """Constructor arguments of vanilla_dynamic.network.DNeRF_Straightforward (network.py:100-149) from a state dict, or
+    None when the file is a static NeRF.  Its keys are NeRF's; what differs is layer 0's fan-in, cat[gamma(x), gamma(t)]:
+    told by the saved `args` (network_type, multires, multires_time) when the checkpoint has them (vanilla_dynamic/model.py:
+    189-199 saves vars(args)), otherwise by a fan-in that is not 3 + 6 L but (3 + 6 L) + (1 + 2 Lt), Lt = 10 preferred."""
+    if "pts_linears.0.weight" not in sd:
+        return None
+    a = infer_nerf_arch(sd)
+    total = a["input_ch"]
+    args = args or {}
+    tc = None
+    if args.get("network_type") == "straightforward":
+        Lt = int(args.get("multires_time", 10))
+        tc = 1 + 2 * Lt if Lt > 0 else 1
+        if not args.get("no_include_input", False) and "multires" in args and int(args.get("i_embed", 0)) == 0:
+            assert total == 3 + 6 * int(args["multires"]) + tc, "checkpoint args and layer-0 fan-in disagree"
+    elif args.get("network_type") is None and (total - 3) % 6 != 0:
+        for Lt in [10] + list(range(9, -1, -1)):
+            if total - (1 + 2 * Lt) >= 3 and (total - (1 + 2 * Lt) - 3) % 6 == 0:
+                tc = 1 + 2 * Lt
+                break
+    if tc is None:
+        return None
+    return dict(D=a["D"], W=a["W"], input_ch=total - tc, input_ch_views=a["input_ch_views"], input_ch_time=tc,
+                output_ch=a["output_ch"], skips=a["skips"], use_viewdirs=a["use_viewdirs"])
+
+
 def _multires(ch, dims=3):
     """L of get_embedder from a channel count dims + 2*L*dims (positional_encoding.py:39-64, include_input=True)."""
     L, rem = divmod(ch - dims, 2 * dims)
@@ -81,7 +108,11 @@ def networks_from_checkpoint(path, device="cuda", precision="fp32"):
     ckpt = read_checkpoint(path)
 
     def build(sd):
-        if is_dnerf(sd):
+        straight = None if is_dnerf(sd) else infer_straight_arch(sd, ckpt.get("args"))
+        if straight is not None:
+            from .vanilla_dynamic.network import DNeRF_Straightforward
+            m = DNeRF_Straightforward(**straight)
+        elif is_dnerf(sd):
             from .vanilla_dynamic.network import DNeRF_Deformation
             from .vanilla_dynamic.positional_encoding import get_embedder
             arch = infer_dnerf_arch(sd)

@@ -87,3 +87,29 @@ def test_bench_finds_its_committed_counter_evidence():
         assert 0.5 < u["mfma_busy_frac"] < 1.0 and 1.5 < u["clock_ghz"] < 2.5, (workload, u)
     table = {"k<1, true, false>": 1, "k<1, true, true>": 2, "j<2>": 3}
     assert bench._kernel_entry(table, "k<1, true>") == 1 and bench._kernel_entry(table, "j<2>") == 3
+
+
+def test_straightforward_checkpoint_is_recognised(tmp_path):
+    """A DNeRF_Straightforward checkpoint has NeRF's keys; checkpoint.networks_from_checkpoint tells it apart by the saved
+    args (vanilla_dynamic/model.py:189-199) or, without them, by layer 0's fan-in (63 + 21 is not 3 + 6 L)."""
+    import torch
+    from nerf_amd import checkpoint
+    import nerf_amd.vanilla_dynamic as vd
+    m = vd.DNeRF_Straightforward(D=4, W=64, input_ch=63, input_ch_views=27, input_ch_time=21, skips=[1], use_viewdirs=True)
+    sd = m.state_dict()
+    arch = checkpoint.infer_straight_arch(sd)
+    assert arch == dict(D=4, W=64, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=4, skips=[1], use_viewdirs=True)
+    assert checkpoint.infer_straight_arch(sd, dict(network_type="straightforward", multires=10, multires_time=10)) == arch
+    assert checkpoint.infer_straight_arch(sd, dict(network_type="deformation")) is None
+    from nerf_amd.network import NeRF
+    assert checkpoint.infer_straight_arch(NeRF(4, 64, 63, 27, 4, [1], True).state_dict()) is None
+    for args in (None, dict(network_type="straightforward", multires=10, multires_time=10, i_embed=0)):
+        path = tmp_path / f"s{0 if args is None else 1}.tar"
+        blob = {"global_step": 7, "network_fn_state_dict": sd, "network_fine_state_dict": sd}
+        if args:
+            blob["args"] = args
+        torch.save(blob, path)
+        got = checkpoint.networks_from_checkpoint(str(path), device="cpu")
+        assert isinstance(got["network_fn"], vd.DNeRF_Straightforward) and isinstance(got["network_fine"], vd.DNeRF_Straightforward)
+        assert got["network_fn"].input_ch_time == 21 and got["global_step"] == 7
+        assert all(torch.equal(a, b) for a, b in zip(got["network_fn"].state_dict().values(), sd.values()))
