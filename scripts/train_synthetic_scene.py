@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Train the whole path on an analytic scene and look at the TRAINED field (every other fixture here is a random-init or a
+scaled random-init net): a unit sphere with a smooth colour pattern on a white background, seen from random poses on the
+lego-style camera sphere.  train.py's loop (4096 random rays per step, 64 + 128 samples, perturb = 1, Adam 5e-4 with the
+exponential decay) on the fused kernels; then a held-out 200x200 view rendered with the fp32, bf16x3 and bf16 kernels:
+PSNR against the analytic image (what the north star's 'PSNR delta <= 0.05 dB' speaks of), and the fp32 image against the
+CPU oracle on the trained weights.  Writes gpurun_out/<round>_trained_scene.json.
+    python scripts/train_synthetic_scene.py [round] [steps] [train_precision]"""
+import json
+import os
+import sys
+import time
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import nerf_fixtures as fx  # noqa: E402
+from nerf_amd.network import NeRF  # noqa: E402
+from nerf_amd.optim import FusedAdam  # noqa: E402
+from nerf_amd.positional_encoding import get_embedder  # noqa: E402
+from nerf_amd.render import render, run_network  # noqa: E402
+from nerf_amd.utils import img2mse, mse2psnr  # noqa: E402
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+tprec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+np.random.seed(0)
+
+
+def shade(ro, rd):
+    """Analytic image: first hit of the unit sphere, colour 0.5 + 0.5 sin(4 p + phase) at the hit point p, else white."""
+    d = rd / np.linalg.norm(rd, axis=-1, keepdims=True)
+    b = (ro * d).sum(-1)
+    disc = b * b - ((ro * ro).sum(-1) - 1.0)
+    hit = disc > 0
+    t = -b - np.sqrt(np.where(hit, disc, 0.0))
+    p = ro + t[..., None] * d
+    col = 0.5 + 0.5 * np.sin(4.0 * p + np.array([0.0, 2.0, 4.0]))
+    return np.where(hit[..., None], col, 1.0).astype(np.float32)
+
+
+H = W = 200
+K, _ = fx.intrinsics(H, W)
+rs = np.random.RandomState(0)
+poses = [fx.pose_spherical(float(rs.uniform(-180, 180)), float(rs.uniform(-80, -10)), 4.0) for _ in range(60)]
+ro_all, rd_all = [], []
+for c2w in poses:
+    o, d = fx.pinhole_rays_np(H, W, K, c2w)
+    ro_all.append(o.reshape(-1, 3))
+    rd_all.append(d.reshape(-1, 3))
+ro_all, rd_all = np.concatenate(ro_all), np.concatenate(rd_all)
+tg_all = shade(ro_all.astype(np.float64), rd_all.astype(np.float64))
+ro_t, rd_t, tg_t = (torch.from_numpy(a).to(dev) for a in (ro_all, rd_all, tg_all))
+
+coarse = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True).to(dev)
+fine = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True).to(dev)
+coarse.train_precision = fine.train_precision = tprec
+e10, _ = get_embedder(10, 0)
+e4, _ = get_embedder(4, 0)
+kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), N_importance=128, network_fine=fine,
+          N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True, ndc=False, lindisp=False)
+lrate = 5e-4
+opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=lrate, betas=(0.9, 0.999))
+N_rand = 4096
+t0 = time.time()
+log = []
+for i in range(steps):
+    idx = torch.randint(0, ro_t.shape[0], (N_rand,), device=dev)
+    rays = torch.stack([ro_t[idx], rd_t[idx]])
+    rgb, _, _, ex = render(H, W, K, chunk=32768, rays=rays, retraw=True, near=2., far=6., perturb=1., raw_noise_std=0., **kw)
+    opt.zero_grad()
+    img_loss = img2mse(rgb, tg_t[idx])
+    (img_loss + img2mse(ex["rgb0"], tg_t[idx])).backward()
+    opt.step()
+    opt.param_groups[0]["lr"] = lrate * (0.1 ** ((i + 1) / 250000.0))
+    if i % 250 == 0 or i == steps - 1:
+        log.append((i, float(mse2psnr(img_loss.detach()))))
+        print(f"step {i}: train PSNR {log[-1][1]:.2f} dB, {time.time() - t0:.0f} s", flush=True)
+torch.cuda.synchronize()
+train_s = time.time() - t0
+
+# held-out view
+c2w = fx.pose_spherical(37.0, -35.0, 4.0)
+o, d = fx.pinhole_rays_np(H, W, K, c2w)
+truth = shade(o.reshape(-1, 3).astype(np.float64), d.reshape(-1, 3).astype(np.float64)).reshape(H, W, 3)
+kw_t = dict(kw, perturb=0., raw_noise_std=0.)
+out = {"scene": "unit sphere, colour 0.5 + 0.5 sin(4p + phase) at the hit point, white background; 60 training views of "
+                f"{H}x{W}, {steps} steps of {N_rand} rays, train_precision {tprec}; held-out {H}x{W} view",
+       "train_seconds": train_s, "ms_per_step_incl_host": 1e3 * train_s / steps, "train_psnr_log": log}
+imgs = {}
+for prec in ("fp32", "bf16x3", "bf16"):
+    coarse.precision = fine.precision = prec
+    with torch.no_grad():
+        rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=torch.from_numpy(c2w[:3, :4]).to(dev), near=2., far=6., **kw_t)
+    imgs[prec] = rgb.cpu().numpy()
+    mse = float(np.mean((imgs[prec] - truth) ** 2))
+    out[prec] = {"psnr_vs_analytic_dB": -10 * np.log10(mse)}
+for prec in ("bf16x3", "bf16"):
+    d_ = np.abs(imgs[prec] - imgs["fp32"])
+    out[prec]["psnr_delta_vs_fp32_dB"] = out[prec]["psnr_vs_analytic_dB"] - out["fp32"]["psnr_vs_analytic_dB"]
+    out[prec]["max_abs_vs_fp32"] = float(d_.max())
+    out[prec]["frac_within_1e-2_of_fp32"] = float((d_.max(-1) <= 1e-2).mean())
+    out[prec]["frac_within_1e-4_of_fp32"] = float((d_.max(-1) <= 1e-4).mean())
+    out[prec]["psnr_between_images_dB"] = float(-10 * np.log10(np.mean(d_ ** 2) + 1e-30))
+# the oracle on the trained weights (test infrastructure; all H*W rays)
+from oracle import oracle as orc  # noqa: E402
+sdc = {k: v.detach().cpu().numpy() for k, v in coarse.state_dict().items()}
+sdf = {k: v.detach().cpu().numpy() for k, v in fine.state_dict().items()}
+rays = orc.build_rays(H, W, K, c2w=c2w[:3, :4], near=2., far=6., use_viewdirs=True)
+want = orc.render_rays(rays, orc.Net(sdc), orc.Net(sdf), N_samples=64, N_importance=128, white_bkgd=True)
+d_ = np.abs(imgs["fp32"].reshape(-1, 3) - want["rgb_map"]).max(-1)
+out["fp32"]["vs_oracle_on_trained_weights"] = {
+    "rgb_max_abs": float(d_.max()), "frac_within_1e-4": float((d_ <= 1e-4).mean()),
+    "psnr_between_images_dB": float(-10 * np.log10(np.mean((imgs["fp32"].reshape(-1, 3) - want["rgb_map"]) ** 2) + 1e-30))}
+print(json.dumps(out))
+os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(R, "gpurun_out", f"{rnd}_trained_scene.json"), "w"), indent=1)
