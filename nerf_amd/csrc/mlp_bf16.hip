@@ -22,6 +22,16 @@ namespace nrf {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// Plain-bf16 kernels: the ENCODED INPUT blocks (gamma(x), gamma(d), gamma(t) and their weight columns) go through the f16
+// MFMA (v_mfma_f32_32x32x16_f16: same rate, same f32 accumulators) instead of the bf16 one.  Encoder values lie in [-1, 1]
+// and scene coordinates within a few units, so f16's range is no concern there, and its 11-bit mantissa cuts the rounding of
+// the inputs and of those weights by 8x.  Measured on a trained field ('A trained field'): input rounding was
+// the largest single term of the bf16 image error.  Hidden activations stay bf16 (range).
+#ifndef NRF_BF16_F16_INPUTS
+#define NRF_BF16_F16_INPUTS 1
+#endif
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
@@ -112,6 +122,8 @@ __global__ void pack_bf16_kernel(BfPackBatch batch, char *stream) {
             }
             const __bf16 hi = (__bf16)w;
             v[j] = lo_part ? (__bf16)(w - (float)hi) : hi;
+            if (NRF_BF16_F16_INPUTS && !a.split && !a.transposed && (B.type == BFB_PE3 || B.type == BFB_PE1))
+                v[j] = __builtin_bit_cast(__bf16, (_Float16)w);      // this block is consumed by the f16 MFMA
         }
         *reinterpret_cast<bf16x8 *>(stream + a.dst + (int64_t)sfrag * kFrag + lane * 16) = v;
     }
@@ -261,6 +273,14 @@ static int bf_pack(const BfPlan &P, void *packed, hipStream_t st) {
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
 }
+// encoded-input pair of the plain-bf16 kernels: f16 (see NRF_BF16_F16_INPUTS)
+__device__ __forceinline__ uint32_t pack2in(float a, float b) {
+#if NRF_BF16_F16_INPUTS
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2));
+#else
+    return pack2(a, b);
+#endif
+}
 // ReLU on a packed bf16 pair: as signed 16-bit integers negative floats are negative, so max(.., 0) clears them
 __device__ __forceinline__ uint32_t relu2(uint32_t p) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
@@ -385,13 +405,20 @@ __device__ __forceinline__ void stream_frags(ST &st, Body &&body) {
 }
 
 // acc[p][t] (+)= W_layer * B(p, s) over the layer's S k-steps; B(p, s) = 8 bf16 of point tile p for k-step s.
-template <int NT_OUT, int S, class BF>
+// k-steps IN_LO .. IN_HI-1 are encoded-input steps: f16 operands on the f16 MFMA (NRF_BF16_F16_INPUTS)
+template <int NT_OUT, int S, int IN_LO = 0, int IN_HI = 0, class BF>
 __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st, BF &&B) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     stream_frags<S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
         const int s = i / NT_OUT, t = i % NT_OUT;
-        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(0, s), s == 0 ? zero : acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(1, s), s == 0 ? zero : acc[1][t], 0, 0, 0);
+        if (NRF_BF16_F16_INPUTS && s >= IN_LO && s < IN_HI) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, B(0, s)), s == 0 ? zero : acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, B(1, s)), s == 0 ? zero : acc[1][t], 0, 0, 0);
+        } else {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(0, s), s == 0 ? zero : acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(1, s), s == 0 ? zero : acc[1][t], 0, 0, 0);
+        }
     });
 }
 
@@ -468,7 +495,7 @@ __device__ __forceinline__ void fill_pe3_bf16(u32x4v (&out)[KS], float x, float 
 #pragma unroll
     for (int k = 0; k < KS; ++k)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) out[k][w] = pack2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
+        for (int w = 0; w < 4; ++w) out[k][w] = pack2in(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
 }
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_cast(bf16x8, v); }
@@ -481,7 +508,7 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
                                          long long *prof = nullptr) {
     (void)prof;
     PROF_T(t0);
-    gemm_layer<NT, S0>(acc, st, b0);
+    gemm_layer<NT, S0, 0, S0>(acc, st, b0);
     PROF_T(t1);
     pack_acts<NT>(hin, acc, true);
     PROF_T(t2);
@@ -489,7 +516,7 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
     for (int l = 1; l < n_trunk; ++l) {
         PROF_T(t3);
         if ((skip_in_mask >> l) & 1)
-            gemm_layer<NT, kBfKsX + 2 * NT>(acc, st, [&](int p, int s) {
+            gemm_layer<NT, kBfKsX + 2 * NT, 0, kBfKsX>(acc, st, [&](int p, int s) {
                 return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
             });
         else
@@ -527,7 +554,7 @@ __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin
     PROF_T(h3);
     PROF_ADD(6, h2, h3);
     f32x16 acc2[2][NT / 2];
-    gemm_layer<NT / 2, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {                      // network.py:58-62
+    gemm_layer<NT / 2, 2 * NT + kBfKsD, 2 * NT, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {   // network.py:58-62
         return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
     });
     u32x4v hv[2][NT];
@@ -1046,7 +1073,7 @@ __device__ __forceinline__ void fill_pe1_bf16(u32x4v (&out)[KS], float t, int h)
 #pragma unroll
     for (int k = 0; k < KS; ++k)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) out[k][w] = pack2(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
+        for (int w = 0; w < 4; ++w) out[k][w] = pack2in(v[8 * k + 2 * w], v[8 * k + 2 * w + 1]);
 }
 
 struct DnerfBf16Args {
@@ -1257,11 +1284,11 @@ __global__ void __launch_bounds__(256, 1) straight_query_fwd_bf16_kernel(const S
         auto in = [&](int p, int s) { return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(tin[p][s >= kBfKsX ? s - kBfKsX : 0]); };
         f32x16 acc[2][NT];
         u32x4v hin[2][2 * NT];
-        gemm_layer<NT, KI>(acc, st, in);                                                       // network.py:168-172
+        gemm_layer<NT, KI, 0, KI>(acc, st, in);                                                // network.py:168-172
         pack_acts<NT>(hin, acc, true);
         for (int l = 1; l < a.n_trunk; ++l) {
             if ((a.skip_in_mask >> l) & 1)                                                     // network.py:176-177
-                gemm_layer<NT, KI + 2 * NT>(acc, st, [&](int p, int s) {
+                gemm_layer<NT, KI + 2 * NT, 0, KI>(acc, st, [&](int p, int s) {
                     return s < KI ? in(p, s < KI ? s : 0) : as_bf(hin[p][s >= KI ? s - KI : 0]);
                 });
             else

@@ -26,6 +26,8 @@ from nerf_amd.utils import img2mse, mse2psnr  # noqa: E402
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+load = os.path.join(R, "gpurun_out", f"{sys.argv[1] if len(sys.argv) > 1 else 'r2'}_trained_scene_weights.pt") \
+    if len(sys.argv) > 4 and sys.argv[4] == "load" else None
 tprec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -69,6 +71,11 @@ opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=lrate, b
 N_rand = 4096
 t0 = time.time()
 log = []
+if load:
+    wts = torch.load(load, weights_only=True)
+    coarse.load_state_dict(wts["coarse"])
+    fine.load_state_dict(wts["fine"])
+    steps = 0
 for i in range(steps):
     idx = torch.randint(0, ro_t.shape[0], (N_rand,), device=dev)
     rays = torch.stack([ro_t[idx], rd_t[idx]])
@@ -84,11 +91,16 @@ for i in range(steps):
 torch.cuda.synchronize()
 train_s = time.time() - t0
 
+if not load:
+  torch.save({"coarse": {k: v.detach().cpu() for k, v in coarse.state_dict().items()},
+            "fine": {k: v.detach().cpu() for k, v in fine.state_dict().items()}},
+           os.path.join(R, "gpurun_out", f"{rnd}_trained_scene_weights.pt"))
 # held-out view
 c2w = fx.pose_spherical(37.0, -35.0, 4.0)
 o, d = fx.pinhole_rays_np(H, W, K, c2w)
 truth = shade(o.reshape(-1, 3).astype(np.float64), d.reshape(-1, 3).astype(np.float64)).reshape(H, W, 3)
 kw_t = dict(kw, perturb=0., raw_noise_std=0.)
+steps = max(steps, 1)
 out = {"scene": "unit sphere, colour 0.5 + 0.5 sin(4p + phase) at the hit point, white background; 60 training views of "
                 f"{H}x{W}, {steps} steps of {N_rand} rays, train_precision {tprec}; held-out {H}x{W} view",
        "train_seconds": train_s, "ms_per_step_incl_host": 1e3 * train_s / steps, "train_psnr_log": log}
@@ -107,6 +119,11 @@ for prec in ("bf16x3", "bf16"):
     out[prec]["frac_within_1e-2_of_fp32"] = float((d_.max(-1) <= 1e-2).mean())
     out[prec]["frac_within_1e-4_of_fp32"] = float((d_.max(-1) <= 1e-4).mean())
     out[prec]["psnr_between_images_dB"] = float(-10 * np.log10(np.mean(d_ ** 2) + 1e-30))
+    pm = d_.max(-1).reshape(-1)
+    out[prec]["abs_vs_fp32_percentiles"] = {q: float(np.percentile(pm, float(q))) for q in ("50", "90", "99", "99.9")}
+    # the same PSNR without the 0.1 % of the pixels that differ most (silhouette rays, where a rounding flips the resampling)
+    keep = pm <= np.percentile(pm, 99.9)
+    out[prec]["psnr_between_images_dB_without_top_0.1pct"] = float(-10 * np.log10(np.mean(d_.reshape(-1, 3)[keep] ** 2) + 1e-30))
 # the oracle on the trained weights (test infrastructure; all H*W rays)
 from oracle import oracle as orc  # noqa: E402
 sdc = {k: v.detach().cpu().numpy() for k, v in coarse.state_dict().items()}
