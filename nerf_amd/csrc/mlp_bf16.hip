@@ -331,9 +331,15 @@ struct WStreamT {
     // the previous chunk, whose stage the copies of the chunk after next may now overwrite).  The caller then issues
     // the four copies one at a time between MFMAs (each VMEM issue stalls the wave; spread out, the matrix pipe
     // covers part of every stall instead of idling through four in a row).
+    // YOUNGER: vector-memory operations known to have been issued AFTER the copies of the chunk beyond the next one's
+    // predecessor -- activation stores of the layer before (stream_frags) -- which may stay in flight as well: without
+    // the allowance the in-order counter makes every first chunk of a layer wait for the previous layer's stores to be
+    // acknowledged by the L2.  A lower bound is safe (it only waits longer); an overestimate is not.
+    template <int YOUNGER = 0>
     __device__ __forceinline__ void publish() {
         // the copies of chunks beyond the next one (4 per chunk and wave, returned in order) may stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 3) * 4) : "memory");
+        static_assert((kStages - 3) * 4 + YOUNGER <= 63, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 3) * 4 + YOUNGER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -368,7 +374,10 @@ using WStreamX3 = WStreamT<NRF_X3_AHEAD>;   // 1.5 MFMAs per fragment instead of
 // the chunk protocol runs -- publish the next chunk mid-chunk, copy requests spread over the following fragment slots,
 // LDS reads kAhead fragments ahead across chunk and layer boundaries.  The layer starts on a chunk boundary;
 // N % kAhead == 0 keeps q's phase static.
-template <int N, class ST, class Body>
+// YOUNGER > 0: that many stores were issued between the previous layer's last copy request and this layer.  At this
+// layer's first two publishes the copies waited for (requested two chunks earlier, i.e. before those stores) are older
+// than the stores, so the stores may stay in flight; from the third publish on the awaited copies are younger than them.
+template <int N, int YOUNGER = 0, class ST, class Body>
 __device__ __forceinline__ void stream_frags(ST &st, Body &&body) {
     constexpr int kAhead = ST::kDepth;
     static_assert(N % kAhead == 0 && N >= kAhead, "fragment count of a layer must be a multiple of the read-ahead");
@@ -381,7 +390,10 @@ __device__ __forceinline__ void stream_frags(ST &st, Body &&body) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int i = 16 * c + f;
-            if (f == pos) st.publish();
+            if (f == pos) {
+                if (YOUNGER > 0 && kStages == 4 && c < 2) st.template publish<YOUNGER>();
+                else st.template publish<0>();
+            }
             {   // copies of the chunk after next: one piece at each of four fragment slots from `pos` on
                 const int span = F - pos, stp = span >= 8 ? 2 : 1;
                 if (span >= 4) {
@@ -425,10 +437,11 @@ __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st
 // bf16x3: acc[t] (+)= W * x with W = Wh + Wl, x = xh + xl (bf16 each) as Wh*xh + Wh*xl + Wl*xh.  The stream holds
 // (hi, residual) fragment pairs; one 32-point tile per wave; all three MFMAs of a pair accumulate into the same tile.
 // BIAS_LAST: the last k-step is the bias step, whose input is the exact constant 1 (residual 0): Wh * 0 is skipped.
-template <int NT_OUT, int S, bool BIAS_LAST = false, class BH, class BL>
+// YOUNGER: stores issued since the previous layer's GEMM (stream_frags)
+template <int NT_OUT, int S, bool BIAS_LAST = false, int YOUNGER = 0, class BH, class BL>
 __device__ __forceinline__ void gemm_layer_x3(f32x16 (&acc)[NT_OUT], WStreamX3 &st, BH &&Bh, BL &&Bl) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    stream_frags<2 * S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
+    stream_frags<2 * S * NT_OUT, YOUNGER>(st, [&](int i, const bf16x8 &a) {
         const int j = i >> 1, s = j / NT_OUT, t = j % NT_OUT;
         if ((i & 1) == 0) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bh(s), s == 0 ? zero : acc[t], 0, 0, 0);
@@ -676,6 +689,54 @@ struct X3Save {
     int lane;
 };
 
+#ifndef NRF_X3_QUAD_STORES
+#define NRF_X3_QUAD_STORES 1
+#endif
+
+// a[i] of lane j (j = lane & 3)  <-  a[j] of lane i of the same lane quad: two rounds of DPP exchanges
+__device__ __forceinline__ void quad_transpose(uint32_t (&a)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {
+        const uint32_t s = o1 ? a[p] : a[p + 1];
+        const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+        a[p] = o1 ? got : a[p];
+        a[p + 1] = o1 ? a[p + 1] : got;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint32_t s = o2 ? a[p] : a[p + 2];
+        const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+        a[p] = o2 ? got : a[p];
+        a[p + 2] = o2 ? a[p + 2] : got;
+    }
+}
+
+// 16-byte stores one call of store_tile_t8_quads per tile issues for nt tiles (the allowance of stream_frags)
+#ifndef NRF_X3_STORE_ALLOWANCE
+#define NRF_X3_STORE_ALLOWANCE 1
+#endif
+constexpr int x3_tile_stores(int nt) { return (NRF_X3_QUAD_STORES && NRF_X3_STORE_ALLOWANCE) ? 4 * nt : 0; }
+
+// One accumulator tile (16 values a lane, register r = channel 32t + (r&3) + 8(r>>2) + 4h of point lane&31) to its T8
+// section.  A T8 line is four channels of eight points: the four registers of a group (r>>2) of a lane quad hold a 4x4
+// block of it, so after a transpose inside the quad every lane owns four consecutive points of one channel and the block
+// goes out as ONE 16-byte store a lane instead of four 4-byte ones -- a quarter of the store instructions, which is what
+// the conversion phase of the 3-term kernels waits on.
+__device__ __forceinline__ void store_tile_t8_quads(__amdgpu_buffer_rsrc_t rsrc, int lane, int C, uint32_t sec, int t,
+                                                    const float (&r)[16]) {
+    const int q = lane & 31, h = lane >> 5;
+    const int voff = (((q >> 3) * C + 4 * h + (q & 3)) * 8 + (q & 4)) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t a[4] = {__float_as_uint(r[4 * g]), __float_as_uint(r[4 * g + 1]), __float_as_uint(r[4 * g + 2]),
+                         __float_as_uint(r[4 * g + 3])};
+        quad_transpose(a, lane);
+        const u32x4 v = {a[0], a[1], a[2], a[3]};
+        buffer_store_b128(v, rsrc, voff, (int)((sec + (32 * t + 8 * g) * 8) * 4));
+    }
+}
+
 // sec: T8 section (floats from the tile base) the f32 values are saved to; gate_slot >= 0: also the ReLU gate bits
 // (bit order of store_gate_bits).  The stores sit in the conversion phase, where the matrix pipe is idle anyway.
 template <int NT, bool TRAIN = false>
@@ -700,10 +761,14 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
             for (int k = 0; k < 16; ++k) asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[k]) : "v"(r[k]));
         }
         if constexpr (TRAIN) {
+#if NRF_X3_QUAD_STORES && !defined(NRF_NO_QUAD_FWD)
+            store_tile_t8_quads(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r);
+#else
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), sv->tb.rsrc, voff,
                                                       (int)((sec + (32 * t + 8 * (k >> 2) + (k & 3)) * 8) * 4), 0);
+#endif
             if (gate_slot >= 0) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) gm[t >> 1] = (gm[t >> 1] << 1) | min(__float_as_uint(r[k]), 1u);
@@ -722,7 +787,7 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
         if (gate_slot >= 0) {
             if constexpr (NT & 1) gm[NT >> 1] <<= 16;
             u32x4 v = {gm[0], gm[1], gm[2], gm[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(v, sv->tb.rsrc, sv->lane * 16, gate_slot * 4, 0);
+            buffer_store_b128(v, sv->tb.rsrc, sv->lane * 16, gate_slot * 4);
         }
     }
 }
@@ -792,13 +857,14 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
     gemm_layer_x3<NT, S0>(acc, st, b0h, b0l);
     pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk, a_mask);
     for (int l = 1; l < n_trunk; ++l) {
+        constexpr int kSt = TRAIN ? x3_tile_stores(NT) : 0;   // the layer before saved its activations
         if ((skip_in_mask >> l) & 1)
-            gemm_layer_x3<NT, kBfKsX + 2 * NT>(
+            gemm_layer_x3<NT, kBfKsX + 2 * NT, false, kSt>(
                 acc, st,
                 [&](int s) { return s < kBfKsX ? as_bf(xh[s < kBfKsX ? s : 0]) : as_bf(hh[s >= kBfKsX ? s - kBfKsX : 0]); },
                 [&](int s) { return s < kBfKsX ? as_bf(xl[s < kBfKsX ? s : 0]) : as_bf(hl[s >= kBfKsX ? s - kBfKsX : 0]); });
         else
-            gemm_layer_x3<NT, 2 * NT + 1, true>(
+            gemm_layer_x3<NT, 2 * NT + 1, true, kSt>(
                 acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                 [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });
         pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk + l * (32 * 32 * NT), a_mask + l * 256);
@@ -813,13 +879,14 @@ __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)
                                                  int64_t n_points, int h, float *raw, const X3Save *sv = nullptr,
                                                  uint32_t a_feat = 0, uint32_t a_hv = 0, int hv_gate_slot = -1) {
     f32x16 acc1[1];
-    gemm_layer_x3<1, 2 * NT>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });      // network.py:56
+    constexpr int kSt = TRAIN ? x3_tile_stores(NT) : 0;   // the last trunk layer saved its activations
+    gemm_layer_x3<1, 2 * NT, false, kSt>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:56
     const float alpha = acc1[0][0] + hb[kHbAlpha];
     gemm_layer_x3<NT, 2 * NT + 1, true>(acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                                   [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });   // network.py:57
     pack_acts_x3<NT, TRAIN>(hh, hl, acc, false, sv, a_feat, -1);
     f32x16 acc2[NT / 2];
-    gemm_layer_x3<NT / 2, 2 * NT + kBfKsD>(                                                                          // network.py:58-62
+    gemm_layer_x3<NT / 2, 2 * NT + kBfKsD, false, kSt>(                                                              // network.py:58-62
         acc2, st,
         [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(dh[s >= 2 * NT ? s - 2 * NT : 0]); },
         [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(dl[s >= 2 * NT ? s - 2 * NT : 0]); });
@@ -942,10 +1009,14 @@ __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl
                 r[k] = __uint_as_float(__float_as_uint(r[k]) & (uint32_t)mask);
             }
         }
+#if NRF_X3_QUAD_STORES && !defined(NRF_NO_QUAD_DGRAD)
+        store_tile_t8_quads(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r);
+#else
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), tg.rsrc, voff,
                                                   (int)((sec + (32 * t + 8 * (k >> 2) + (k & 3)) * 8) * 4), 0);
+#endif
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             uint32_t hi, lo;
@@ -1017,13 +1088,15 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
                 u32x4v vh[NT], vl[NT];
                 finish_grad_x3<NT / 2, false, true, false>(vh, vl, g2, hvgate, wb, 0u, 0.f, tg, (uint32_t)tl.g_hv, W / 2);
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
-                gemm_layer_x3<NT, NT>(acc, st, [&](int s) { return as_bf(vh[s]); }, [&](int s) { return as_bf(vl[s]); });
+                gemm_layer_x3<NT, NT, false, x3_tile_stores(NT / 2)>(acc, st, [&](int s) { return as_bf(vh[s]); },
+                                                                     [&](int s) { return as_bf(vl[s]); });
             }
             finish_grad_x3<NT, true, false, false>(hh, hl, acc, nogate, wb, 0u, 0.f, tg, (uint32_t)tl.g_feat, W + 32);
             const float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);          // d/d(alpha): alpha_linear's wgrad
             // through feature_linear and alpha_linear (network.py:56-57) -> d/d(h_{D-1}), then that layer's ReLU
-            gemm_layer_x3<NT, 2 * NT>(acc, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });
+            gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT)>(acc, st, [&](int s) { return as_bf(hh[s]); },
+                                                                 [&](int s) { return as_bf(hl[s]); });
             finish_grad_x3<NT, true, true, true>(hh, hl, acc, gate, wb, (uint32_t)pl.alpha_vec, gr.w, tg,
                                                  (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (32 * W), W);
         } else {
@@ -1042,7 +1115,8 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
         // trunk in reverse (network.py:49-53): g_{l-1} = gate_{l-1} . (W_l[:, hidden]^T g_l)
         for (int l = pl.n_trunk - 1; l >= 1; --l) {
             gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);       // in flight during the GEMM
-            gemm_layer_x3<NT, 2 * NT>(acc, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });
+            gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT)>(acc, st, [&](int s) { return as_bf(hh[s]); },
+                                                                 [&](int s) { return as_bf(hl[s]); });
             finish_grad_x3<NT, true, true, false>(hh, hl, acc, gate, wb, 0u, 0.f, tg, (uint32_t)tl.g_trunk + (l - 1) * (32 * W), W);
         }
     }

@@ -487,6 +487,17 @@ __device__ __forceinline__ void store_acc_t8(const TBuf &tb, uint32_t sec, const
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// EVERY 16-byte buffer store goes through here.  The store reads its data registers over more than one cycle, and a VALU
+// write to them in the slots right after it lands in the stored value: seen on gfx950 as the last two dwords of the
+// transposed T8 stores of the 3-term dgrad kernel replaced, run to run differently, wherever the compiler had placed a
+// v_pk_mov to those registers directly behind the store.  The compiler pads that gap only for stores whose soffset is not
+// a register; these have one.  The asm keeps the data registers live across two idle slots (and, through its memory
+// clobber, behind the store), so nothing can be written to them before the store has read them.
+__device__ __forceinline__ void buffer_store_b128(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 0);
+    asm volatile("s_nop 2" : "+v"(v) : : "memory");
+}
+
 // group G's share of store_acc_t8: registers 4(G&3) .. +3 of tile G>>2 (the ones group G's MFMAs read)
 template <int NT>
 __device__ __forceinline__ void store_acc_t8_group(const TBuf &tb, uint32_t sec, const f32x16 (&v)[NT], int G) {
@@ -513,7 +524,7 @@ __device__ __forceinline__ void gate_bits_group(const TBuf &tb, uint32_t slot, c
     if (G == 4 * NT - 1) {
         if constexpr (NT & 1) m[NT >> 1] <<= 16;
         u32x4 v = {m[0], m[1], m[2], m[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, tb.rsrc, lane * 16, (int)(slot * 4), 0);
+        buffer_store_b128(v, tb.rsrc, lane * 16, (int)(slot * 4));
     }
 }
 
@@ -531,7 +542,7 @@ __device__ __forceinline__ void store_gate_bits(const TBuf &tb, uint32_t slot, c
         }
     if constexpr (NT & 1) m[NT >> 1] <<= 16;
     u32x4 v = {m[0], m[1], m[2], m[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(v, tb.rsrc, lane * 16, (int)(slot * 4), 0);
+    buffer_store_b128(v, tb.rsrc, lane * 16, (int)(slot * 4));
 }
 __device__ __forceinline__ u32x4 load_gate_bits(const TBuf &tb, uint32_t slot, int lane) {
     return __builtin_amdgcn_raw_buffer_load_b128(tb.rsrc, lane * 16, (int)(slot * 4), 0);
