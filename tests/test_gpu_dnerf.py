@@ -341,6 +341,52 @@ def test_render_dnerf_row_shards_equal_whole(parts):
                 assert torch.equal(torch.cat(shards, 0).reshape(H, W, 5), whole)
 
 
+def test_bf16x3_training_gradients_repeat_and_match_f32(parts):
+    """One backward pass of the D-NeRF training loss at train_precision = 'bf16x3', twice: bitwise the same gradients
+    both times, and every parameter's gradient within 1e-2 of its scale of the exact-f32 kernels' (measured ~1e-4).
+    Regression test of the 16-byte-store hazard: with a VALU write scheduled directly behind a
+    buffer_store_dwordx4 the deformation net's activation gradients came out wrong in 32 of 256 channels, and differently
+    from run to run."""
+    import importlib.util
+    import os
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    model = vd.DNeRF_Deformation(D=8, W=256, D_deform=8, W_deform=256, input_ch=63, input_ch_views=27, input_ch_time=21,
+                                 output_ch=4, skips=[4], use_viewdirs=True, zero_canonical=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_dnerf_state(33, peaky=False, dx_scale=1.0).items()},
+                          strict=True)
+    model = model.cuda()
+    model.embed_fn = embed_fn
+    qfn = lambda i, v, t, f: vd.run_network_dnerf(i, v, t, f, embed_fn, embeddirs_fn, embed_time, 65536)  # noqa: E731
+    kw = dict(network_fn=model, network_query_fn=qfn, N_samples=64, perturb=0., N_importance=128, network_fine=None,
+              white_bkgd=True, raw_noise_std=0., use_viewdirs=True)
+    K, _ = fx.intrinsics(400, 400)
+    ro, rd, times, target = mg.dtraj_batches()
+    sl = slice(0, mg.DTRAJ_RAYS)
+
+    def grads(precision):
+        model.train_precision = precision
+        rgb, _, _, extras = vd.render_dnerf(400, 400, K, dev(times[sl]), chunk=32768,
+                                            rays=torch.stack([dev(ro[sl]), dev(rd[sl])], 0), retraw=True, near=2., far=6., **kw)
+        model.zero_grad()
+        loss = torch.mean((rgb - dev(target[sl])) ** 2) + torch.mean((extras["rgb0"] - dev(target[sl])) ** 2)
+        loss = loss + mg.DTRAJ_REG * (torch.mean(extras["dx"] ** 2) + torch.mean(extras["dx0"] ** 2))
+        loss.backward()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    exact, a, b = grads("fp32"), grads("bf16x3"), grads("bf16x3")
+    worst = 0.0
+    for k in exact:
+        assert torch.equal(a[k], b[k]), f"{k}: two identical bf16x3 backward passes differ"
+        scale = float(exact[k].abs().max())
+        worst = max(worst, float((a[k] - exact[k]).abs().max()) / max(scale, 1e-30))
+    print(f"bf16x3 vs f32 D-NeRF parameter gradients: worst max-abs difference {worst:.2e} of the gradient's scale")
+    assert worst < 1e-2, worst
+
+
 @pytest.mark.parametrize("train_precision", ["fp32", "bf16x3"])
 def test_dnerf_training_trajectory_vs_reference(parts, train_precision):
     """Twenty consecutive steps of vanilla_dynamic/train.py:237-277 (render_dnerf with per-ray times -> mse(rgb) +
