@@ -761,7 +761,7 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
             for (int k = 0; k < 16; ++k) asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[k]) : "v"(r[k]));
         }
         if constexpr (TRAIN) {
-#if NRF_X3_QUAD_STORES && !defined(NRF_NO_QUAD_FWD)
+#if NRF_X3_QUAD_STORES
             store_tile_t8_quads(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r);
 #else
 #pragma unroll
@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl
                 r[k] = __uint_as_float(__float_as_uint(r[k]) & (uint32_t)mask);
             }
         }
-#if NRF_X3_QUAD_STORES && !defined(NRF_NO_QUAD_DGRAD)
+#if NRF_X3_QUAD_STORES
         store_tile_t8_quads(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r);
 #else
 #pragma unroll
