@@ -41,7 +41,11 @@ def mfma_util(src, dst, rnd):
         if per:
             util[w] = per
     if len(util) > 1:
-        with open(os.path.join(dst, f"{rnd}_mfma_util.json"), "w") as f:
+        out_path = os.path.join(dst, f"{rnd}_mfma_util.json")
+        if os.path.exists(out_path):        # a partial run (one workload re-profiled) keeps the round's other workloads
+            for k, v in json.load(open(out_path)).items():
+                util.setdefault(k, v)
+        with open(out_path, "w") as f:
             json.dump(util, f, indent=1, sort_keys=True)
         print(json.dumps(util, indent=1, sort_keys=True)[:4000])
 
