@@ -156,6 +156,13 @@ def test_random_net_parameter_gradients(seed, train_precision):
             assert err < 1e-2, (k, cfg, n_rays * S, err)
         worst = max(worst, err)
     print(f"gradient fuzz {seed} {train_precision}: worst error {worst:.2e} (fp32: max element / scale; bf16x3: Frobenius)")
+    # the same pass again gives the same bits (slab reduction in a fixed order, no atomics; and nothing timing-dependent
+    # such as the 16-byte store hazard of DESIGN.md section 9 in any instantiation these cases reach)
+    first = {k: dict(net.named_parameters())[k].grad.clone() for k in used}
+    net.zero_grad()
+    (net.query_points(pts, dirs if cfg["use_viewdirs"] else None, S, L, Lv) * g).sum().backward()
+    for k in used:
+        assert torch.equal(first[k], dict(net.named_parameters())[k].grad), (k, cfg, "second pass differs")
 
 
 @pytest.mark.parametrize("seed", range(6))
