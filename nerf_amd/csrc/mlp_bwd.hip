@@ -316,6 +316,9 @@ __device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[4][4], float (&bs)[4],
 // (the piece of group s holds points 0-3 of every channel in its first 512 bytes, points 4-7 in the second).  At three
 // MFMAs of 32 cycles per tile pair a full super-block asks for ~21 B/clk/CU of operands, twice what HBM delivers to 256
 // CUs: this kernel is HBM-bound (64 FLOP/B), the matrix pipe waits, and the conversion VALU work fills the gaps.
+#ifndef NRF_WG_X3_PIPE
+#define NRF_WG_X3_PIPE 4      // VALU ops pinned behind each MFMA of a step (0: leave the order to the scheduler)
+#endif
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
@@ -381,6 +384,24 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[x][y], 0, 0, 0);
                 }
             }
+#if NRF_WG_X3_PIPE
+            // the split results are only used after the next barrier, and pure arithmetic gets sunk to its use: pin it here
+#pragma unroll
+            for (int x = 0; x < NA; ++x) asm volatile("" : "+v"(An[x].hi), "+v"(An[x].lo), "+v"(Rn[x]));
+#pragma unroll
+            for (int y = 0; y < KA; ++y) asm volatile("" : "+v"(Bn[y].hi), "+v"(Bn[y].lo));
+            // A wave issues in order: an MFMA behind a busy matrix pipe holds back everything after it, so the split of the
+            // next step's operands only overlaps the MFMAs if it sits BETWEEN them in program order.  Left alone the
+            // scheduler built one of the two unrolled steps as 36 MFMAs in a row with the whole split after the barrier
+            // (matrix pipe idle for ~250 VALU ops).  Pin the shape: the 16 LDS reads first, then per MFMA its share of the
+            // ~190 VALU ops.
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NA + KA), 0);
+#pragma unroll
+            for (int i = 0; i < 3 * NA * KA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NRF_WG_X3_PIPE, 0);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
