@@ -331,10 +331,10 @@ struct WStreamT {
     // the previous chunk, whose stage the copies of the chunk after next may now overwrite).  The caller then issues
     // the four copies one at a time between MFMAs (each VMEM issue stalls the wave; spread out, the matrix pipe
     // covers part of every stall instead of idling through four in a row).
-    // YOUNGER: vector-memory operations known to have been issued AFTER the copies of the chunk beyond the next one's
-    // predecessor -- activation stores of the layer before (stream_frags) -- which may stay in flight as well: without
-    // the allowance the in-order counter makes every first chunk of a layer wait for the previous layer's stores to be
-    // acknowledged by the L2.  A lower bound is safe (it only waits longer); an overestimate is not.
+    // YOUNGER: vector-memory operations known to have been issued AFTER the copies this publish waits for and, like the
+    // youngest chunk's four copies, allowed to stay in flight: the activation stores of the layer before (stream_frags).
+    // Without the allowance the in-order counter makes a layer's first chunks wait until the L2 has acknowledged the
+    // previous layer's stores.  A lower bound is safe (it only waits longer); an overestimate is not.
     template <int YOUNGER = 0>
     __device__ __forceinline__ void publish() {
         // the copies of chunks beyond the next one (4 per chunk and wave, returned in order) may stay in flight
