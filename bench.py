@@ -7,8 +7,9 @@ A step = one full render of a synthetic 800x800 view (BASELINE.json configs[1]: 
 nets, multires 10/4, view directions, white background, near/far 2/6, chunk 32768, perturb=0) through
 nerf_amd.render.render().  Weights are seeded random-init (+ the "peaky" head scaling of SURVEY 8c),
 poses come from the spherical-pose formula: data is synthetic, there is no dataset offline.
-With N > 1 (launched by torch.distributed.run) the image's rows are sharded over the ranks and one
-gather returns (rgb, disp, acc) to rank 0: strong scaling of one image.
+With N > 1 the image's rows are sharded over N ranks (one process per GPU) and one gather returns (rgb, disp, acc)
+to rank 0: strong scaling of one image.  `python bench.py --gpus N` starts the ranks itself (torch.distributed.run
+as a child process); under an external launcher (WORLD_SIZE set) it runs as one rank and checks WORLD_SIZE == N.
 
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the fused PE+MLP query,
 MFMA-bound) from HIP-event durations of every query launch inside the timed region; `cpu_baseline` is
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="train workload: fp32 = the reference's arithmetic; bf16x3 = three bf16 MFMAs per f32 product "
                          "(f32-grade results, gradients within the same 2e-3 of the reference's autograd)")
+    ap.add_argument("--n-importance", type=int, default=128,
+                    help="fine samples per ray (render / fern workloads): 128 = the metric; 64 = what configs/fern.txt ships")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-path", action="store_true", help="use the multi-GPU row-sharded code path even with one GPU")
     ap.add_argument("--graph", action="store_true",
@@ -161,6 +164,11 @@ def multi_gpu_report(torch, dist, world, device, local_ms, events, key):
             key: round(sum(ms) / max(len(ms), 1), 3) if ms else None}
 
 
+# parameter tensors of one D=8 / W=256 NeRF with view directions (network.py:29-44): weights and biases, 595 844 in all
+_NERF_PARAM_SIZES = [63 * 256, 256] + [256 * 256, 256] * 4 + [319 * 256, 256] + [256 * 256, 256] * 2 + \
+    [256 * 256, 256, 256, 1, 283 * 128, 128, 128 * 3, 3]
+
+
 def hbm_kernels(torch, device, n_rays=32768, reps=20):
     """Achieved GB/s of the sampling / compositing kernels at the render chunk size: algorithmic bytes per launch
     (inputs read once + outputs written once) over the HIP-event duration, `reps` back-to-back launches."""
@@ -180,6 +188,10 @@ def hbm_kernels(torch, device, n_rays=32768, reps=20):
         "composite_fwd_kernel (S=192)": (lambda: ops.composite_fwd(raw192, z192, rays[:, 3:6], None, True),
                                          4 * (4 * 192 + 192 + 3 + 3 + 1 + 1 + 192 + 1)),
     }
+    g_rgb = torch.randn(n_rays, 3, device=device)
+    # the backward recomputes the forward's quantities: it reads raw, z, d and the rgb gradient, writes the raw gradient
+    cases["composite_bwd_kernel (S=192)"] = (lambda: ops.composite_bwd(raw192, z192, rays[:, 3:6], g_rgb, white_bkgd=True),
+                                             4 * (4 * 192 + 192 + 3 + 3 + 4 * 192))
     out = {}
     for name, (fn, bytes_per_ray) in cases.items():
         fn()
@@ -193,6 +205,24 @@ def hbm_kernels(torch, device, n_rays=32768, reps=20):
         gbs = bytes_per_ray * n_rays / (us * 1e-6) / 1e9
         out[name] = {"us_per_launch": round(us, 2), "bytes_per_ray": bytes_per_ray, "GB/s": round(gbs, 1),
                      "frac_of_8TB/s": round(gbs / 8000.0, 4)}
+    # the fused Adam step over both nets' parameters: reads p, g, m, v and writes p, m, v = 28 B/parameter
+    from nerf_amd.optim import FusedAdam
+    params = [torch.nn.Parameter(torch.randn(n, device=device)) for n in _NERF_PARAM_SIZES * 2]
+    for p in params:
+        p.grad = torch.randn_like(p)
+    opt = FusedAdam(params, lr=5e-4)
+    opt.step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        opt.step()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    nparam = sum(p.numel() for p in params)
+    gbs = 28 * nparam / (us * 1e-6) / 1e9
+    out["adam_kernel (both nets, 1 191 688 parameters in 48 tensors)"] = {
+        "us_per_launch": round(us, 2), "bytes_per_parameter": 28, "GB/s": round(gbs, 1), "frac_of_8TB/s": round(gbs / 8000.0, 4)}
     return out
 
 
@@ -243,6 +273,29 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
                              "roofline_frac": tf / (PEAK_BF16_MFMA_TFLOPS / 3), "achieved_TFLOPs": tf,
                              "workload": f"the same {args.size}x{args.size} render, three bf16 MFMAs per f32 product on "
                                          "hi/residual operands (meets the f32 tolerance of 1e-4; FLOP/s f32-equivalent)"}
+    # BASELINE.json configs[3]: the LLFF-fern-shaped 1008x756 NDC view, at the metric's 64+128 samples in all three
+    # arithmetics and at the 64+64 configs/fern.txt:10-11 ships (SURVEY 8d asks for both)
+    for prec, n_imp, key in (("fp32", 128, "fern_ndc_fp32"), ("bf16x3", 128, "fern_ndc_bf16x3"), ("bf16", 128, "fern_ndc_bf16"),
+                             ("fp32", 64, "fern_ndc_fp32_64+64")):
+        coarse.precision = fine.precision = prec
+        fH, fW, fstep = make_render_step(args, torch, device, coarse, fine, True, n_imp)
+        fstep(0)
+        torch.cuda.synchronize()
+        timer.events.clear()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for i in range(3):
+            fstep(i + 1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        timer.enabled = False
+        q_ms, q_pts, q_n = timer.summary()
+        tf = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12
+        pk = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3}[prec]
+        also[key] = {"value": fH * fW / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f32" if prec == "fp32" else prec,
+                     "roofline_frac": tf / pk, "achieved_TFLOPs": tf, "points_per_launch": q_pts / max(q_n, 1),
+                     "workload": f"LLFF-fern-shaped {fW}x{fH} NDC render, 64+{n_imp} samples, D=8 W=256 coarse+fine, {prec}"}
+    timer.events.clear()
     coarse.precision = fine.precision = "fp32"
     a = copy.copy(args)
     a.steps, a.warmup = 10, 3
@@ -261,6 +314,53 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
     also["dnerf_train_step"] = bench_dnerf.run_dnerf_train(a, torch, device)
     also["dnerf_train_step_bf16x3"] = bench_dnerf.run_dnerf_train(a, torch, device, train_precision="bf16x3")
     return also
+
+
+def make_render_step(args, torch, device, coarse, fine, fern, n_importance=128, world=1, rank=0, timings=None):
+    """(H, W, step): step(i) renders pose i of the workload -- the lego-shaped size x size view (configs[1]) or the
+    LLFF-fern-shaped 1008x756 NDC view (configs[3]: factor 4, forward-facing pose, no white background) -- through
+    nerf_amd.render.render(), or as this rank's row shard + one gather when world > 1."""
+    import nerf_fixtures as fx
+    from nerf_amd import parallel
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render, run_network
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=n_importance,
+              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
+              raw_noise_std=0., ndc=False, lindisp=False)
+    H = W = args.size
+    K, _ = fx.intrinsics(H, W)
+    if fern:
+        H, W = 756, 1008
+        K = np.array([[815.0, 0, 0.5 * W], [0, 815.0, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+        kw.update(ndc=True, white_bkgd=False)
+    near, far = (0., 1.) if fern else (2., 6.)
+    frame_graph = []
+
+    def step(i):
+        if fern:   # identity rotation, small lateral motion per step
+            c2w = torch.eye(4)[:3, :4].clone()
+            c2w[0, 3] = 0.02 * i
+            c2w = c2w.to(device)
+        else:
+            c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
+        with torch.no_grad():
+            if world == 1 and args.graph:
+                if not frame_graph:
+                    from nerf_amd.render import RenderGraph
+                    frame_graph.append(RenderGraph(H, W, K, chunk=32768, near=near, far=far, **kw))
+                return frame_graph[0](c2w)[0]
+            if world == 1 and not args.sharded_path:
+                rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=near, far=far, **kw)
+                return rgb
+
+            def rows(row0, nrows):
+                kw2 = {k: v for k, v in kw.items() if k not in ("ndc", "use_viewdirs")}
+                return parallel.render_rows(H, W, K, c2w, row0, nrows, chunk=32768, ndc=kw["ndc"], near=near, far=far,
+                                            use_viewdirs=True, **kw2)
+            return parallel.render_sharded(rows, H, W, rank, world, timings=timings)
+    return H, W, step
 
 
 def cpu_baseline(n_rays):
@@ -285,16 +385,77 @@ def cpu_baseline(n_rays):
             "sample": f"{n_rays} random rays of the 800x800 view, 64+128 samples, oracle/liborc.so (OpenMP), {dt:.1f} s"}
 
 
+def needs_launch(gpus, env):
+    """True when this process is the PARENT of an N > 1 run: --gpus N asked for more than one rank and no launcher has set
+    WORLD_SIZE yet (the driver's `python bench.py --gpus N` form)."""
+    return gpus > 1 and "WORLD_SIZE" not in env
+
+
+def launcher_command(gpus, argv, port, script=None):
+    """The child command of an N > 1 run: torch.distributed.run with one rank per GPU on this node, same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(gpus, argv, script=None, env=None):
+    """`python bench.py --gpus N` without an external launcher: start the N ranks as a CHILD process (never exec: this
+    process may not be replaced once anything has touched the GPU, and nothing here has), relay the ranks' stdout
+    (rank 0's JSON line) and return the child's exit code -- non-zero as well when no line with n_gpus == N came back,
+    so an N-GPU run can never be mistaken for the one-GPU measurement.  No torch.cuda call happens in the parent."""
+    import subprocess
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = launcher_command(gpus, argv, _free_port(), script)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    seen = False
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                seen = seen or json.loads(line).get("n_gpus") == gpus
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc == 0 and not seen:
+        print(f"bench.py: the {gpus}-rank run ended without a result line carrying n_gpus == {gpus}", file=sys.stderr)
+        return 3
+    return rc
+
+
+def check_world(gpus, world):
+    """Every rank: the process group's size IS the --gpus argument, or the run stops before it measures anything."""
+    if world != gpus:
+        print(f"bench.py: --gpus {gpus} but WORLD_SIZE is {world}: refusing to report a {world}-rank run as {gpus} GPUs "
+              f"(start `python bench.py --gpus {gpus}` without a launcher, or give the launcher --nproc-per-node {gpus})",
+              file=sys.stderr)
+        sys.exit(2)
+
+
 def main():
     args = parse()
+    if needs_launch(args.gpus, os.environ):
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    check_world(args.gpus, world)
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # NRF_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # collectives staged by gloo); the measured configuration is always nccl (= RCCL), one GPU per rank
     backend = os.environ.get("NRF_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {torch.cuda.device_count()} "
+              "(NRF_BENCH_BACKEND=gloo rehearses the multi-rank path with ranks sharing a GPU)", file=sys.stderr)
+        sys.exit(2)
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -326,47 +487,11 @@ def main():
     x3 = args.precision == "bf16x3"
     # bf16x3 issues three bf16 MFMAs per f32 product: its roofline in f32-equivalent FLOP/s is a third of the bf16 peak
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 3 if x3 else PEAK_F32_MFMA_TFLOPS)
-    e10, _ = get_embedder(10, 0)
-    e4, _ = get_embedder(4, 0)
-    kw = dict(network_query_fn=lambda i, v, f: run_network(i, v, f, e10, e4, 65536), perturb=0., N_importance=128,
-              network_fine=fine, N_samples=64, network_fn=coarse, use_viewdirs=True, white_bkgd=True,
-              raw_noise_std=0., ndc=False, lindisp=False)
-    H = W = args.size
-    K, _ = fx.intrinsics(H, W)
     fern = args.workload == "fern"
-    if fern:   # BASELINE.json configs[3]: LLFF fern at factor 4, NDC rays, forward-facing pose, no white background
-        H, W = 756, 1008
-        K = np.array([[815.0, 0, 0.5 * W], [0, 815.0, 0.5 * H], [0, 0, 1]], dtype=np.float32)
-        kw.update(ndc=True, white_bkgd=False)
-    near, far = (0., 1.) if fern else (2., 6.)
     timer = QueryTimer(torch)
     timer.install()
-
-    frame_graph = []
-
-    def step(i):
-        if fern:   # identity rotation, small lateral motion per step
-            c2w = torch.eye(4)[:3, :4].clone()
-            c2w[0, 3] = 0.02 * i
-            c2w = c2w.to(device)
-        else:
-            c2w = torch.from_numpy(fx.pose_spherical(-180.0 + 9.0 * i, -30.0, 4.0)[:3, :4]).to(device)
-        with torch.no_grad():
-            if world == 1 and args.graph:
-                if not frame_graph:
-                    from nerf_amd.render import RenderGraph
-                    frame_graph.append(RenderGraph(H, W, K, chunk=32768, near=near, far=far, **kw))
-                return frame_graph[0](c2w)[0]
-            if world == 1 and not args.sharded_path:
-                rgb, disp, acc, _ = render(H, W, K, chunk=32768, c2w=c2w, near=near, far=far, **kw)
-                return rgb
-            def rows(row0, nrows):
-                kw2 = {k: v for k, v in kw.items() if k not in ("ndc", "use_viewdirs")}
-                return parallel.render_rows(H, W, K, c2w, row0, nrows, chunk=32768, ndc=kw["ndc"], near=near, far=far,
-                                            use_viewdirs=True, **kw2)
-            return parallel.render_sharded(rows, H, W, rank, world, timings=timings)
-
     timings = {}
+    H, W, step = make_render_step(args, torch, device, coarse, fine, fern, args.n_importance, world, rank, timings)
 
     def fence():
         if world > 1:
@@ -396,10 +521,10 @@ def main():
         if args.graph and world == 1:
             # a replayed graph has no per-launch events: price the query kernel against the WHOLE frame time (a lower
             # bound of its rate; the default, ungraphed run measures the kernel itself)
-            q_ms, q_pts, q_n = 1e3 * dt, n_rays * (64 + 192) * args.steps, args.steps
+            q_ms, q_pts, q_n = 1e3 * dt, n_rays * (64 + 64 + args.n_importance) * args.steps, args.steps
         achieved = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12 if q_ms > 0 else 0.0
         out = {
-            "metric": "rays/sec at 64+128 samples/ray (render)",
+            "metric": f"rays/sec at 64+{args.n_importance} samples/ray (render)",
             "value": n_rays * args.steps / dt,
             "unit": "rays/s",
             "n_gpus": world,
@@ -412,7 +537,8 @@ def main():
             "dtype": "bf16" if bf16 else ("bf16x3" if x3 else "f32"),
             "data": "synthetic",
             "config": {"workload": (f"LLFF-fern-shaped {W}x{H} NDC render" if fern else f"lego-shaped {H}x{W} test-view render")
-                       + f", 64+128 samples, D=8 W=256 coarse+fine, {args.precision}, chunk 32768", "rays_per_step": n_rays,
+                       + f", 64+{args.n_importance} samples, D=8 W=256 coarse+fine, {args.precision}, chunk 32768",
+                       "rays_per_step": n_rays,
                        "parallelism": f"rows sharded over {world} GPU(s), one gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,

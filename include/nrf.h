@@ -150,7 +150,7 @@ int nrf_query_bwd_input(const nrf_net_t *net, const nrf_embed_t *emb, const floa
  * and kernels as nrf_query_bwd, but `gbuf` and `slab` live in a 64 MiB file-scope device array inside the library (each GPU
  * the library runs on holds its copy until the process ends) and the wgrad reduction uses <= 8 partial slabs per GEMM
  * instead of <= 256, so the results agree with nrf_query_bwd's to f32 summation order (1e-5 of a gradient's scale), not
- * bit for bit.  Limit: nrf_train_grads_floats(net, n) + 8-chunk slabs must fit the array -- 2048 points at D = 8,
+ * bit for bit.  Limit: nrf_train_grads_floats(net, n) + 8-chunk slabs must fit the array -- 3040 points (95 tiles) at D = 8,
  * W = 256 (the error string of a refused call states the limit for the given network); larger passes use nrf_query_bwd.
  * Calls no hipMalloc / hipFree.  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
  * threads) race; serialise them. */

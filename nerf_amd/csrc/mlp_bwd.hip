@@ -945,9 +945,12 @@ extern "C" int nrf_query_bwd_static(const nrf_net_t *net, const nrf_embed_t *emb
                                     const float *acts, int64_t n_points, const nrf_net_t *grads, void *stream) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd_static: null descriptor");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd_static: negative n_points");
-    const int64_t need_g = (nrf_train_grads_floats(net, n_points) + 63) & ~(int64_t)63;     // keep `slab` 256-byte aligned
+    const int64_t raw_g = nrf_train_grads_floats(net, n_points);
     const int64_t need_s = slab_floats(net, n_points, kStaticMaxChunks);
-    if (need_g < 0 || need_s < 0) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_static: unsupported network shape");
+    if (raw_g < 0 || need_s < 0)      // tested BEFORE the rounding below, which would turn the -1 of an unsupported shape into 0
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_static: unsupported network shape (D %d, W %d: the backward "
+                         "kernels take W a multiple of 32 up to 256 and D <= 16)", net->D, net->W);
+    const int64_t need_g = (raw_g + 63) & ~(int64_t)63;     // keep `slab` 256-byte aligned
     if (need_g + need_s > kStaticScratchFloats) {
         // the slab part is constant beyond kStaticMaxChunks tiles; gbuf grows by g_tile floats per 32 points
         const int64_t per_tile = nrf_train_grads_floats(net, 32);

@@ -390,14 +390,15 @@ class PackedTimeNet(PackedNet):
     def query(self, *a, **k):
         raise NotImplementedError("the time net alone is only evaluated for training; rendering uses nrf_dnerf_query_fwd")
 
-    def query_train(self, pts, times, pts_per_ray=1, times_per_point=False):
-        """-> (dx [P,3], saved workspace)."""
+    def query_train(self, pts, times, pts_per_ray=1, times_per_point=False, acts=None):
+        """-> (dx [P,3], saved workspace).  `acts`: a workspace of an earlier call to reuse when it is large enough."""
         self.refresh()
         pts, times = _f32(pts, "pts"), _f32(times, "times")
         P = pts.shape[0]
         dx = torch.empty((P, 3), device=pts.device, dtype=torch.float32)
         n = _lib.lib().nrf_train_acts_floats(C.byref(self.net), P)
-        acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
+        if acts is None or acts.numel() < max(n, 1) or acts.device != pts.device:
+            acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
         check(_lib.lib().nrf_dnerf_time_fwd_train(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
                                                   _ptr(times), P, int(pts_per_ray), int(bool(times_per_point)),
                                                   _ptr(dx), _ptr(acts), _stream()), "nrf_dnerf_time_fwd_train")

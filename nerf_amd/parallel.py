@@ -114,7 +114,14 @@ class BucketedGradAllReduce:
     both are latency-bound on xGMI, the first one now costs nothing.
 
     Semantics are those of one flat all-reduce (train.py's single-process gradient, averaged over ranks): a bucket whose
-    hook never fired on this rank (a parameter without gradient) is reduced at finish() with zeros in its place."""
+    hook never fired on this rank (a parameter without gradient) is reduced at finish() with zeros in its place, and the
+    parameter then HAS a gradient (the mean over the ranks, zero if no rank produced one; Adam moves it by its momentum
+    where a single process would have skipped a grad=None parameter -- FlatGradAllReduce does the same).
+
+    Collectives are issued in BUCKET-INDEX order on every rank, whatever order the hooks fire in: a bucket that becomes
+    ready before a lower-numbered one is queued until that one has been launched (finish() launches what is left, in
+    order), so ranks whose graphs differ cannot pair all-reduces of different buckets.  One backward() per finish(): a
+    gradient arriving for a bucket whose all-reduce is already in flight raises."""
 
     def __init__(self, buckets, group=None, min_world=2):
         self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
@@ -122,6 +129,8 @@ class BucketedGradAllReduce:
         self.min_world = min_world   # 1: run the collectives even in a one-rank group (single-GPU test of the stream logic)
         self._pending = [set(id(p) for p in b) for b in self.buckets]
         self._inflight = {}          # bucket index -> (flat, work, grads)
+        self._ready = set()          # buckets whose gradients are complete but that wait for a lower index to launch
+        self._next = 0               # lowest bucket index not launched yet
         self.launch_order = []       # bucket indices in the order their all-reduces were started (tests read this)
         self._side = None
         self._hooks = []
@@ -131,11 +140,22 @@ class BucketedGradAllReduce:
 
     def _make_hook(self, bi):
         def hook(p):
+            if bi in self._inflight:
+                raise RuntimeError("BucketedGradAllReduce: a gradient arrived for a bucket whose all-reduce is already in "
+                                   "flight (a second backward() before finish()?): call finish() after every backward()")
             pend = self._pending[bi]
             pend.discard(id(p))
-            if not pend and bi not in self._inflight:
-                self._launch(bi)
+            if not pend:
+                self._ready.add(bi)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Start every ready bucket whose predecessors have all been started: index order on every rank."""
+        while self._next < len(self.buckets) and self._next in self._ready:
+            self._ready.discard(self._next)
+            self._launch(self._next)
+            self._next += 1
 
     def _overlapped(self, t):
         return t.is_cuda and dist.get_backend(self.group) == "nccl"
@@ -173,9 +193,9 @@ class BucketedGradAllReduce:
             self._reset()
             return []
         world = dist.get_world_size(self.group)
-        for bi in range(len(self.buckets)):                  # buckets whose last hook never fired on this rank
-            if bi not in self._inflight:
-                self._launch(bi)
+        for bi in range(self._next, len(self.buckets)):      # queued buckets and those whose last hook never fired here
+            self._launch(bi)
+        self._next = len(self.buckets)
         for bi, (flat, work, grads) in self._inflight.items():
             if work is not None:
                 work.wait()                                  # the current stream waits for the collective
@@ -193,6 +213,8 @@ class BucketedGradAllReduce:
     def _reset(self):
         self._pending = [set(id(p) for p in b) for b in self.buckets]
         self._inflight = {}
+        self._ready = set()
+        self._next = 0
         self.launch_order = []
 
     def remove(self):

@@ -272,6 +272,9 @@ class DNeRF_Straightforward(nn.Module):
         return out, torch.zeros_like(input_pts[:, :3])
 
 
+_TWO_LAUNCH_POINTS = 65536      # points per time-net launch of the two-launch inference chain (bounds its workspace)
+
+
 class DNeRF_Deformation(nn.Module):
     def __init__(self, D=8, W=256, D_deform=8, W_deform=256, input_ch=3, input_ch_views=3, input_ch_time=1,
                  output_ch=4, skips=[4], skips_deform=[4], use_viewdirs=True, zero_canonical=True,
@@ -411,7 +414,20 @@ class DNeRF_Deformation(nn.Module):
         """The chain as time-net launch -> x + dx -> canonical launch (the kernels of the training path, nothing kept):
         same arithmetic as the fused kernel, for nets of different widths."""
         tnet = self._time_packed(L, Lt)
-        dx, _ = tnet.query_train(pts, times, pts_per_ray, times_per_point)
+        # the time net runs on the kernel instantiation that saves activations (~10 KB per point at D = 8, W = 256, which
+        # inference never reads): in slices of whole rays of at most _TWO_LAUNCH_POINTS points through ONE reused
+        # workspace (0.66 GB), not over the 6.3 M points of a 32768-ray fine chunk at once (60 GB)
+        P = pts.shape[0]
+        step = max(1, _TWO_LAUNCH_POINTS // pts_per_ray) * pts_per_ray
+        if P <= step:
+            dx, _ = tnet.query_train(pts, times, pts_per_ray, times_per_point)
+        else:
+            dx, acts = torch.empty((P, 3), device=pts.device, dtype=torch.float32), None
+            for p0 in range(0, P, step):
+                p1 = min(P, p0 + step)
+                t = times[p0:p1] if times_per_point else times[p0 // pts_per_ray:-(-p1 // pts_per_ray)]
+                dx[p0:p1], acts = tnet.query_train(pts[p0:p1], t, pts_per_ray, times_per_point, acts=acts)
+            del acts
         if self.zero_canonical:   # network.py:315-322: a netchunk whose FIRST point has t == 0 skips the time net
             P = pts.shape[0]
             t_pt = times if times_per_point else times.repeat_interleave(pts_per_ray)

@@ -305,6 +305,21 @@ def test_deformation_chain_with_unequal_widths(W, D):
             raw, dx = run(nc)
         assert np.abs(dx.cpu().numpy() - want_dx).max() < 2e-5 * max(np.abs(want_dx).max(), 1e-3)
         assert np.abs(raw.cpu().numpy() - want_raw).max() < 2e-4 * np.abs(want_raw).max()
+    # the time-net half runs in slices of whole rays through one reused workspace (bounded memory at a 32768-ray chunk):
+    # slices of 2 rays (ragged last slice) must give the unsliced result bit for bit, per-ray and per-point times alike
+    from nerf_amd.vanilla_dynamic import network as vnet
+    with torch.no_grad():
+        whole = [t.clone() for t in run(S)]
+        per_point = [t.clone() for t in model.query_points(dev(pts.reshape(-1, 3)), dev(dirs), dev(np.repeat(times, S)), S, True,
+                                                            S, 10, 4, 10)]
+        cap, vnet._TWO_LAUNCH_POINTS = vnet._TWO_LAUNCH_POINTS, 2 * S + 5
+        try:
+            sliced = run(S)
+            sliced_pp = model.query_points(dev(pts.reshape(-1, 3)), dev(dirs), dev(np.repeat(times, S)), S, True, S, 10, 4, 10)
+        finally:
+            vnet._TWO_LAUNCH_POINTS = cap
+    for a, b in zip(whole + per_point, list(sliced) + list(sliced_pp)):
+        assert torch.equal(a.reshape(b.shape), b)
     model.precision = "bf16"
     with torch.no_grad(), pytest.raises(ValueError, match="same width"):
         run(S)

@@ -137,6 +137,45 @@ def test_c1_view_all_pixels(g2, precision):
     assert p > 80.0, p
 
 
+@pytest.fixture(scope="module")
+def g3():
+    return np.load(os.path.join(ROOT, "tests", "golden", "static3.npz"))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_c1_fine_pass_on_the_references_sample_positions(g3, precision):
+    """Kernel error and conditioning separated by a test (round 3): static3.npz holds the coarse weights the imported
+    reference handed to sample_pdf on each of the 10 000 rays of configs[0] (render.py:215-220).  From THOSE the
+    resampling kernel must give the reference's fine samples bit for bit (checksums), and on these identical positions
+    the fine pass -- points, fused query, compositor -- is held to the north star's 1e-4 on rgb, acc AND disp with no
+    allowance for the reference's own rounding (test_c1_view_all_pixels needs one for acc / disp end to end, because
+    sample_pdf amplifies 1e-7 differences of the coarse weights)."""
+    from nerf_amd import ops
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import raw2outputs, run_network
+    coarse, fine = static_nets(precision)
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "static2.npz"))
+    rays = ops.gen_rays(100, 100, g2["c1_K"], dev(g2["c1_c2w"]), 2., 6., True, False, None)
+    z64 = ops.sample_coarse(rays, 64)
+    w = np.zeros((10000, 64), np.float32)
+    w[:, 1:-1] = g3["c1_coarse_weights_mid"]             # sample_pdf reads weights[..., 1:-1] only (render.py:220)
+    zs, z_vals, z_std = ops.sample_fine(z64, dev(w), 128, None, want_samples=True)
+    zs_h = host(zs)
+    assert np.array_equal(zs_h.astype(np.float64).sum(-1), g3["c1_z_samples_sum"])          # bit-exact fine samples
+    assert np.array_equal(zs_h[:, [0, 63, 127]], g3["c1_z_samples_first_last"])
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    with torch.no_grad():
+        raw = run_network(ops.points(rays, z_vals), rays[:, -3:], fine, e10, e4, 65536)
+        rgb, disp, acc, _, _ = raw2outputs(raw, z_vals, rays[:, 3:6], 0., True)
+    print(f"configs[0] fine pass on the reference's positions, {precision}:")
+    for k, got in (("rgb", rgb), ("acc", acc), ("disp", disp)):
+        e = float(np.abs(host(got).reshape(g3[f"c1_{k}"].shape) - g3[f"c1_{k}"]).max())
+        print(f"  {k}: {e:.2e}")
+        assert e <= 1e-4, (k, e)
+    assert float(np.abs(host(z_std).reshape(-1) - g3["c1_z_std"].reshape(-1)).max()) <= 2e-6
+
+
 def test_c1_view_bf16(g2):
     """bf16 variant on the same view: 1e-2 max-abs on RGB / acc, and the north star's PSNR delta <= 0.05 dB against a
     common target at the README's quality level (no lego data offline: SURVEY 8c)."""

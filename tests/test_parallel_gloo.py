@@ -104,6 +104,33 @@ def _bucket_worker(rank, world, port, out):
         got = [p.grad.clone() for p in plain]
         assert lonely.grad is not None and float(lonely.grad.abs().max()) == 0.0
         ar.remove()
+        # rank-dependent graphs: rank 1's loss never reaches the fine net, so there only the coarse bucket (index 1) fires
+        # during the backward.  It must wait for bucket 0 (launched at finish() with zeros) -- every rank issues the
+        # collectives in index order, or buckets of different sizes would be paired.  Buckets listed coarse-first as well:
+        # the later-ready bucket 0 holds back the earlier-ready bucket 1.
+        for buckets in ([list(fine.parameters()), list(coarse.parameters())],
+                        [list(coarse.parameters()), list(fine.parameters())]):
+            ar = parallel.BucketedGradAllReduce(buckets)
+            for p in plain:
+                p.grad = None
+            ((coarse(x) ** 2).mean() + ((fine(x) ** 2).mean() if rank == 0 else 0.0)).backward()
+            local_fine = fine.weight.grad.clone() if rank == 0 else torch.zeros_like(fine.weight)   # write-back is finish()'s
+            order = ar.finish()
+            assert order == [0, 1], order
+            dist.all_reduce(local_fine)                  # after finish(): no collective of the test between the buckets'
+            assert torch.allclose(fine.weight.grad, local_fine / world, atol=1e-7)
+            ar.remove()
+        # one backward() per finish(): a second backward meets a bucket already in flight
+        ar = parallel.BucketedGradAllReduce([list(fine.parameters()), list(coarse.parameters())])
+        loss_fn().backward()
+        try:
+            loss_fn().backward()
+            raised = False
+        except RuntimeError as e:
+            raised = "finish()" in str(e)
+        ar.finish()
+        ar.remove()
+        assert raised
         if rank == 0:
             out["orders"] = orders
             out["max_err"] = max(float((a - b).abs().max()) for a, b in zip(got, want))

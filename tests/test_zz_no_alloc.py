@@ -57,11 +57,14 @@ def _both(net, n_rays, seed):
     # the allocation-free one: inputs and outputs only
     got, gs = _grad_desc(pk.params)
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # two counters: torch's caching allocator (sees only torch) and the DRIVER's free bytes (hipMemGetInfo: a hipMalloc
+    # inside the library would show here; the scratch array was resolved by the warm-up call of the test)
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     _lib.check(lib.nrf_query_bwd_static(C.byref(pk.net), C.byref(pk.emb), ops._ptr(pk.packed), ops._ptr(g_raw),
                                         ops._ptr(acts), P, C.byref(gs), _stream()), "nrf_query_bwd_static")
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before, (free_before, torch.cuda.mem_get_info()[0])
     return ref, got
 
 
@@ -79,7 +82,8 @@ def test_static_backward_matches_twice():
     net = NeRF(8, 256, 63, 27, 5, [4], True)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fx.make_nerf_state(21, peaky=True).items()})
     net = net.cuda()
-    _compare(*_both(net, 32, 1))     # 2048 points: the limit for this network (64 tiles, 8 slabs of 8 tiles)
+    _both(net, 1, 0)                 # warm-up: resolves the scratch symbol on this device (and loads the kernels)
+    _compare(*_both(net, 47, 1))     # 3008 points: 94 of the 95 tiles this network may pass (8 slabs of 12 tiles)
     _compare(*_both(net, 5, 2))      # then 320 points: 10 tiles, the scratch still holds the first call's data
     # no view directions, W = 128, a ragged tile
     small = NeRF(4, 128, 63, 0, 4, [2], False)
@@ -106,11 +110,18 @@ def test_static_backward_rejects_what_does_not_fit():
     pk = net._packed((0, 10, 4))
     pk.refresh()
     lib = _lib.lib()
-    P = 4096 * 64
     dummy = torch.zeros(16, device="cuda")
     _, gs = _grad_desc(pk.params)
-    rc = lib.nrf_query_bwd_static(C.byref(pk.net), C.byref(pk.emb), ops._ptr(pk.packed), ops._ptr(dummy), ops._ptr(dummy),
-                                  P, C.byref(gs), C.c_void_p(0))
-    assert rc == 2      # NRF_ERR_UNSUPPORTED, nothing launched
-    msg = lib.nrf_last_error_string().decode()
-    assert "static scratch" in msg and "at most" in msg, msg
+    for P in (4096 * 64, 3041):          # far beyond, and one point past the limit the header documents (3040)
+        rc = lib.nrf_query_bwd_static(C.byref(pk.net), C.byref(pk.emb), ops._ptr(pk.packed), ops._ptr(dummy),
+                                      ops._ptr(dummy), P, C.byref(gs), C.c_void_p(0))
+        assert rc == 2      # NRF_ERR_UNSUPPORTED, nothing launched
+        msg = lib.nrf_last_error_string().decode()
+        assert "static scratch" in msg and "at most 3040 points" in msg, msg
+    # a shape the backward kernels do not take (W not a multiple of 32) is refused as such, whatever its size
+    bad = _lib.NrfNet()
+    C.memmove(C.byref(bad), C.byref(pk.net), C.sizeof(bad))
+    bad.W = 100
+    rc = lib.nrf_query_bwd_static(C.byref(bad), C.byref(pk.emb), ops._ptr(pk.packed), ops._ptr(dummy), ops._ptr(dummy), 64,
+                                  C.byref(gs), C.c_void_p(0))
+    assert rc == 2 and "unsupported network shape" in lib.nrf_last_error_string().decode()
