@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="render", choices=["render", "fern", "train", "dnerf"])
     ap.add_argument("--size", type=int, default=800, help="image side (render workload)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
-                    help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f16", "bf16x3"],
+                    help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant; "
+                         "f16 = the same 16-bit kernel with f16 hidden operands (saturating)")
     ap.add_argument("--train-rays", type=int, default=4096, help="global ray batch of the train workload")
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="train workload: fp32 = the reference's arithmetic; bf16x3 = three bf16 MFMAs per f32 product "
@@ -98,7 +99,7 @@ class QueryTimer:
                 return out
             cls.query = timed
         wrap(ops.PackedNet)
-        wrap(ops.PackedNetBf16)
+        wrap(ops.PackedNetBf16)     # PackedNetF16 inherits the wrapped query
         wrap(ops.PackedNetBf16x3)
 
     def summary(self):
@@ -255,6 +256,24 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
     also["render_bf16"] = {"value": args.size * args.size / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "bf16",
                            "roofline_frac": tf / PEAK_BF16_MFMA_TFLOPS, "achieved_TFLOPs": tf,
                            "workload": f"the same {args.size}x{args.size} render, bf16 MFMA variant (tolerance 1e-2)"}
+    # the 16-bit kernel with f16 hidden operands (saturating): same rate class, 8x finer rounding
+    coarse.precision = fine.precision = "f16"
+    step(0)
+    torch.cuda.synchronize()
+    timer.events.clear()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(3):
+        step(i + 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    timer.enabled = False
+    q_ms, q_pts, q_n = timer.summary()
+    tf = q_pts * FLOP_PER_POINT / (q_ms * 1e-3) / 1e12
+    also["render_f16"] = {"value": args.size * args.size / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt, "dtype": "f16",
+                          "roofline_frac": tf / PEAK_BF16_MFMA_TFLOPS, "achieved_TFLOPs": tf,
+                          "workload": f"the same {args.size}x{args.size} render, 16-bit kernel with f16 hidden operands "
+                                      "(v_mfma_f32_32x32x16_f16, saturating conversion; tolerance 1e-2)"}
     # and at f32-grade accuracy on the bf16 pipe (bf16x3)
     coarse.precision = fine.precision = "bf16x3"
     step(0)
@@ -483,7 +502,7 @@ def main():
 
     coarse, fine = build_nets(torch, device)
     coarse.precision = fine.precision = args.precision
-    bf16 = args.precision == "bf16"
+    bf16 = args.precision in ("bf16", "f16")     # the 16-bit kernels: same matrix rate (bf16 / f16 MFMA), same roofline
     x3 = args.precision == "bf16x3"
     # bf16x3 issues three bf16 MFMAs per f32 product: its roofline in f32-equivalent FLOP/s is a third of the bf16 peak
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 3 if x3 else PEAK_F32_MFMA_TFLOPS)
@@ -534,7 +553,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16" if bf16 else ("bf16x3" if x3 else "f32"),
+            "dtype": args.precision if bf16 else ("bf16x3" if x3 else "f32"),
             "data": "synthetic",
             "config": {"workload": (f"LLFF-fern-shaped {W}x{H} NDC render" if fern else f"lego-shaped {H}x{W} test-view render")
                        + f", 64+{args.n_importance} samples, D=8 W=256 coarse+fine, {args.precision}, chunk 32768",
@@ -546,7 +565,9 @@ def main():
                                                 "query_fwd_bf16_kernel<8, true>" if bf16
                                                 else ("query_fwd_bf16x3_kernel<8, true>" if x3
                                                       else "query_fwd_kernel<8, false, false, false>")),
-                         "kernel": "query_fwd_bf16_kernel<8,true> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)" if bf16
+                         "kernel": ("query_fwd_bf16_kernel<8,true,F16> (fused PE + MLP, f16 MFMA with saturating conversion, "
+                                    "LDS-shared weight stream)" if args.precision == "f16" else
+                                    "query_fwd_bf16_kernel<8,true> (fused PE + MLP, bf16 MFMA, LDS-shared weight stream)") if bf16
                          else ("query_fwd_bf16x3_kernel<8,true> (fused PE + MLP, 3 bf16 MFMAs per f32 product; FLOP/s are "
                                "f32-equivalent, peak = bf16 peak / 3)" if x3
                                else "query_fwd_kernel<8,false> (fused PE + MLP, f32 MFMA)"),

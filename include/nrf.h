@@ -26,7 +26,7 @@ extern "C" {
 
 /* bumped whenever a struct layout or a signature changes (200: nrf_net_t carries the LayerNorm parameters); a binding
  * compares nrf_version() with the NRF_VERSION it was written against before passing structs */
-#define NRF_VERSION 200
+#define NRF_VERSION 210
 #define NRF_MAX_D 16
 
 typedef enum {
@@ -225,6 +225,15 @@ int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb);
 int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
 int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
                        const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
+
+/* The same 16-bit variant with f16 instead of bf16 for the hidden activations and their weights as well (the encoded inputs
+ * are f16 in both): same MFMA rate and f32 accumulation (v_mfma_f32_32x32x16_f16), 11 mantissa bits instead of 8.  Range is
+ * what bf16 buys, so this variant saturates: activations and weights beyond +-65504 are clamped to it (round-to-nearest
+ * conversion + packed clamp).  Same stream size (nrf_mlp_bf16_packed_bytes) and arguments; `packed` must come from
+ * nrf_mlp_f16_pack_weights.  No counterpart in the reference.  Inference only. */
+int nrf_mlp_f16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream);
+int nrf_query_fwd_f16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                      const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream);
 
 /* D-NeRF training (autograd of vanilla_dynamic/network.py:307-341, the loss.backward() of vanilla_dynamic/train.py):
  *   forward : dx  = nrf_dnerf_time_fwd_train(time net; saves acts_t);   x' = x + dx   (caller; dx := 0 where the

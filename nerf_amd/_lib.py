@@ -30,7 +30,7 @@ class NrfEmbed(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 200     # include/nrf.h NRF_VERSION
+ABI_VERSION = 210     # include/nrf.h NRF_VERSION
 
 _SIGS = {
     "nrf_version": (C.c_int, []),
@@ -58,6 +58,8 @@ _SIGS = {
     "nrf_mlp_bf16_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_mlp_bf16_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_query_fwd_bf16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),
+    "nrf_mlp_f16_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
+    "nrf_query_fwd_f16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),
     "nrf_query_fwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp, vp]),
     "nrf_query_fwd_train_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp,
                                              vp, vp]),

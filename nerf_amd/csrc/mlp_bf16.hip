@@ -81,6 +81,7 @@ struct BfLayer {
     int32_t split;   // bf16x3: every fragment is followed by its residual fragment, lo = bf16(w - float(bf16(w)))
     int32_t transposed;   // backward chain: rows = W's INPUT channels col0 + out (n_out valid), contraction over W's output
                           // channels (blk.ncols of them): the fragment holds W^T
+    int32_t f16;          // the f16 variant: EVERY block (hidden weights and the bias step too) is consumed by the f16 MFMA
     BfBlock blk[3];
     int64_t dst;   // byte offset in the stream
 };
@@ -124,6 +125,8 @@ __global__ void pack_bf16_kernel(BfPackBatch batch, char *stream) {
             v[j] = lo_part ? (__bf16)(w - (float)hi) : hi;
             if (NRF_BF16_F16_INPUTS && !a.split && !a.transposed && (B.type == BFB_PE3 || B.type == BFB_PE1))
                 v[j] = __builtin_bit_cast(__bf16, (_Float16)w);      // this block is consumed by the f16 MFMA
+            if (a.f16)    // saturating: a weight beyond f16's range stays finite (the activations are clamped the same way)
+                v[j] = __builtin_bit_cast(__bf16, (_Float16)fminf(fmaxf(w, -65504.0f), 65504.0f));
         }
         *reinterpret_cast<bf16x8 *>(stream + a.dst + (int64_t)sfrag * kFrag + lane * 16) = v;
     }
@@ -139,10 +142,12 @@ struct BfPlan {
     BfBiasEntry bias[8];
     int n = 0, nbias = 0;
     int split = 0;      // bf16x3 stream: hi and residual fragments interleaved
+    int f16 = 0;        // the f16 variant's stream (BfLayer::f16)
     int64_t bytes = 0;
     void add(const float *W, const float *b, int ld, int n_out, int nt_out, int tail, BfBlock b0, BfBlock b1 = {}, BfBlock b2 = {}) {
         BfLayer &L = layer[n++];
         L.W = W; L.b = b; L.ld = ld; L.n_out = n_out; L.nt_out = nt_out; L.tail = tail; L.split = split; L.transposed = 0;
+        L.f16 = f16;
         L.blk[0] = b0; L.blk[1] = b1; L.blk[2] = b2;
         L.nblk = 1 + (b1.type != BFB_NONE) + (b2.type != BFB_NONE);
         L.dst = bytes;
@@ -286,6 +291,21 @@ __device__ __forceinline__ uint32_t relu2(uint32_t p) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
 }
 
+// The f16 variant of the plain 16-bit kernels (F16 = true; `precision = "f16"`): hidden activations and their weights in
+// f16 as well.  Same matrix rate and the same f32 accumulators as bf16; 11 mantissa bits instead of 8, so all three
+// rounding terms of the image error (inputs, weights, activations) are 8x smaller.  What bf16 buys is range, so the
+// conversion SATURATES: round-to-nearest v_cvt_pk_f16_f32, ReLU as a signed 16-bit max (as for bf16), then an unsigned
+// 16-bit min against 65504 on the now non-negative patterns -- +inf and NaN patterns included -- one more packed op per
+// pair.  (v_cvt_pkrtz_f16_f32 saturates for free but rounds toward zero: a -2^-11 bias per layer that a ReLU chain
+// compounds.)  The one layer without a ReLU (feature_linear) clamps in f32 before the conversion.
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sat2h(uint32_t p) {      // p: two non-negative f16 patterns
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, p), (u16x2){0x7BFF, 0x7BFF}));
+}
+
 // The weight stream as seen by one wave.  LDS holds FOUR 16 KiB stages: chunk c is consumed from stage c%4 while
 // chunk c+1 is already complete in the next stage and chunks c+2, c+3 are in flight into the other two (the mid-chunk
 // wait leaves the youngest chunk's four copies outstanding: loads return in order).  Two chunks in flight cover an L2
@@ -418,12 +438,12 @@ __device__ __forceinline__ void stream_frags(ST &st, Body &&body) {
 
 // acc[p][t] (+)= W_layer * B(p, s) over the layer's S k-steps; B(p, s) = 8 bf16 of point tile p for k-step s.
 // k-steps IN_LO .. IN_HI-1 are encoded-input steps: f16 operands on the f16 MFMA (NRF_BF16_F16_INPUTS)
-template <int NT_OUT, int S, int IN_LO = 0, int IN_HI = 0, class BF>
+template <int NT_OUT, int S, int IN_LO = 0, int IN_HI = 0, bool F16 = false, class BF>
 __device__ __forceinline__ void gemm_layer(f32x16 (&acc)[2][NT_OUT], WStream &st, BF &&B) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     stream_frags<S * NT_OUT>(st, [&](int i, const bf16x8 &a) {
         const int s = i / NT_OUT, t = i % NT_OUT;
-        if (NRF_BF16_F16_INPUTS && s >= IN_LO && s < IN_HI) {
+        if (F16 || (NRF_BF16_F16_INPUTS && s >= IN_LO && s < IN_HI)) {
             const f16x8 ah = __builtin_bit_cast(f16x8, a);
             acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, B(0, s)), s == 0 ? zero : acc[0][t], 0, 0, 0);
             acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, B(1, s)), s == 0 ? zero : acc[1][t], 0, 0, 0);
@@ -453,7 +473,7 @@ __device__ __forceinline__ void gemm_layer_x3(f32x16 (&acc)[NT_OUT], WStreamX3 &
 }
 
 // accumulators -> next layer's B fragments: k-step 2t+e = registers 8e..8e+7 of tile t, packed pairwise
-template <int NT>
+template <int NT, bool F16 = false>
 __device__ __forceinline__ void pack_acts(u32x4v (&hin)[2][2 * NT], const f32x16 (&acc)[2][NT], bool relu) {
     // One wave per SIMD: a dependent VALU chain (read -> cvt -> max through the same temporaries) issues at a
     // third of the rate of independent instructions.  So: 16 reads, then 8 converts, then 8 max, pinned in that
@@ -467,6 +487,26 @@ __device__ __forceinline__ void pack_acts(u32x4v (&hin)[2][2 * NT], const f32x16
 #pragma unroll
             for (int k = 0; k < 16; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r[k]) : "a"(acc[p][t][k]));
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (F16) {
+                if (!relu) {   // no ReLU, no unsigned clamp: saturate in f32 (feature_linear only, once per net)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) r[k] = __builtin_amdgcn_fmed3f(r[k], -65504.0f, 65504.0f);
+                }
+#pragma unroll
+                for (int w = 0; w < 8; ++w) c[w] = pack2h(r[2 * w], r[2 * w + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (relu) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) c[w] = relu2(c[w]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) c[w] = sat2h(c[w]);
+                }
+#pragma unroll
+                for (int w = 0; w < 8; ++w) hin[p][2 * t + (w >> 2)][w & 3] = c[w];
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int w = 0; w < 8; ++w) c[w] = pack2(r[2 * w], r[2 * w + 1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -515,29 +555,29 @@ __device__ __forceinline__ bf16x8 as_bf(const u32x4v &v) { return __builtin_bit_
 
 // Trunk of one net (network.py:48-53): layer 0 on S0 encoded k-steps B0(p, s), then the hidden layers, each followed
 // by the conversion of its outputs into the next layer's B fragments.
-template <int NT, int S0, class B0>
+template <int NT, int S0, bool F16 = false, class B0>
 __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v (&xin)[2][kBfKsX],
                                          const u32x4v &one, WStream &st, int n_trunk, int skip_in_mask, B0 &&b0,
                                          long long *prof = nullptr) {
     (void)prof;
     PROF_T(t0);
-    gemm_layer<NT, S0, 0, S0>(acc, st, b0);
+    gemm_layer<NT, S0, 0, S0, F16>(acc, st, b0);
     PROF_T(t1);
-    pack_acts<NT>(hin, acc, true);
+    pack_acts<NT, F16>(hin, acc, true);
     PROF_T(t2);
     PROF_ADD(1, t0, t1); PROF_ADD(2, t1, t2);
     for (int l = 1; l < n_trunk; ++l) {
         PROF_T(t3);
         if ((skip_in_mask >> l) & 1)
-            gemm_layer<NT, kBfKsX + 2 * NT, 0, kBfKsX>(acc, st, [&](int p, int s) {
+            gemm_layer<NT, kBfKsX + 2 * NT, 0, kBfKsX, F16>(acc, st, [&](int p, int s) {
                 return s < kBfKsX ? as_bf(xin[p][s < kBfKsX ? s : 0]) : as_bf(hin[p][s >= kBfKsX ? s - kBfKsX : 0]);
             });
         else
-            gemm_layer<NT, 2 * NT + 1>(acc, st, [&](int p, int s) {
+            gemm_layer<NT, 2 * NT + 1, 0, 0, F16>(acc, st, [&](int p, int s) {
                 return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one);
             });
         PROF_T(t4);
-        pack_acts<NT>(hin, acc, true);
+        pack_acts<NT, F16>(hin, acc, true);
         PROF_T(t5);
         PROF_ADD(1, t3, t4); PROF_ADD(2, t4, t5);
     }
@@ -546,7 +586,7 @@ __device__ __forceinline__ void bf_trunk(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][
 // View-direction head of the canonical net (network.py:56-65) -> (rgb + alpha) of both point tiles, stored by lane half 0.
 // `din` = gamma(d), built by the caller BEFORE the trunk: 16 registers held through it cost nothing, while building it here
 // (its sincos temporaries on top of the live feature operand) spilled 60 registers.
-template <int NT>
+template <int NT, bool F16 = false>
 __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin)[2][2 * NT], const u32x4v &one, WStream &st,
                                               const float *hb, const u32x4v (&din)[2][kBfKsD], const int64_t (&pp)[2],
                                               const int64_t (&pc)[2], int64_t n_points, int pts_per_ray, int h, float *raw,
@@ -556,24 +596,24 @@ __device__ __forceinline__ void bf_views_head(f32x16 (&acc)[2][NT], u32x4v (&hin
     auto Hb = [&](int p, int s) { return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(one); };
     auto Hn = [&](int p, int s) { return as_bf(hin[p][s]); };
     f32x16 acc1[2][1];
-    gemm_layer<1, 2 * NT>(acc1, st, Hn);                                                   // network.py:56
+    gemm_layer<1, 2 * NT, 0, 0, F16>(acc1, st, Hn);                                        // network.py:56
     const float ab = hb[kHbAlpha];
     const float alpha0 = acc1[0][0][0] + ab, alpha1 = acc1[1][0][0] + ab;
     PROF_T(h1);
     PROF_ADD(5, h0, h1);
-    gemm_layer<NT, 2 * NT + 1>(acc, st, Hb);                                               // network.py:57
-    pack_acts<NT>(hin, acc, false);
+    gemm_layer<NT, 2 * NT + 1, 0, 0, F16>(acc, st, Hb);                                    // network.py:57
+    pack_acts<NT, F16>(hin, acc, false);
     PROF_T(h2);
     PROF_T(h3);
     PROF_ADD(6, h2, h3);
     f32x16 acc2[2][NT / 2];
-    gemm_layer<NT / 2, 2 * NT + kBfKsD, 2 * NT, 2 * NT + kBfKsD>(acc2, st, [&](int p, int s) {   // network.py:58-62
+    gemm_layer<NT / 2, 2 * NT + kBfKsD, 2 * NT, 2 * NT + kBfKsD, F16>(acc2, st, [&](int p, int s) {   // network.py:58-62
         return s < 2 * NT ? as_bf(hin[p][s < 2 * NT ? s : 0]) : as_bf(din[p][s >= 2 * NT ? s - 2 * NT : 0]);
     });
     u32x4v hv[2][NT];
-    pack_acts<NT / 2>(hv, acc2, true);
+    pack_acts<NT / 2, F16>(hv, acc2, true);
     PROF_T(h4);
-    gemm_layer<1, NT>(acc1, st, [&](int p, int s) { return as_bf(hv[p][s]); });            // network.py:64
+    gemm_layer<1, NT, 0, 0, F16>(acc1, st, [&](int p, int s) { return as_bf(hv[p][s]); });   // network.py:64
     PROF_T(h5);
     PROF_ADD(7, h4, h5);
     if (h == 0) {
@@ -599,7 +639,7 @@ struct Bf16Args {
 
 
 // VIEWS is a template parameter: with both heads in one kernel the allocator spilled another 49 registers.
-template <int NT, bool VIEWS>
+template <int NT, bool VIEWS, bool F16 = false>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -613,8 +653,8 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
     const float *hb = reinterpret_cast<const float *>(a.stream + a.stream_bytes);
 
     const int64_t ntiles = (a.n_points + 255) >> 8;
-    u32x4v one;   // the constant-1 channel of a bias k-step: element 0 of lane half 0
-    one[0] = h == 0 ? 0x3F80u : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
+    u32x4v one;   // the constant-1 channel of a bias k-step: element 0 of lane half 0 (1.0 as bf16, or as f16)
+    one[0] = h == 0 ? (F16 ? 0x3C00u : 0x3F80u) : 0u; one[1] = 0; one[2] = 0; one[3] = 0;
 
 #ifdef NRF_BF16_PROFILE
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -642,16 +682,16 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
         PROF_ADD(0, ta, tb);
         f32x16 acc[2][NT];
         u32x4v hin[2][2 * NT];
-        bf_trunk<NT, kBfKsX>(acc, hin, xin, one, st, a.n_trunk, a.skip_in_mask,
-                             [&](int p, int s) { return as_bf(xin[p][s]); }, prof);               // network.py:48-53
+        bf_trunk<NT, kBfKsX, F16>(acc, hin, xin, one, st, a.n_trunk, a.skip_in_mask,
+                                  [&](int p, int s) { return as_bf(xin[p][s]); }, prof);          // network.py:48-53
         PROF_T(tc);
         if constexpr (VIEWS) {
-            bf_views_head<NT>(acc, hin, one, st, hb, din, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
+            bf_views_head<NT, F16>(acc, hin, one, st, hb, din, pp, pc, a.n_points, a.pts_per_ray, h, a.raw, prof);
             PROF_T(td);
             PROF_ADD(3, tc, td);
         } else {
             f32x16 acc1[2][1];
-            gemm_layer<1, 2 * NT>(acc1, st, [&](int p, int s) { return as_bf(hin[p][s]); });       // network.py:67
+            gemm_layer<1, 2 * NT, 0, 0, F16>(acc1, st, [&](int p, int s) { return as_bf(hin[p][s]); });   // network.py:67
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -1546,17 +1586,24 @@ extern "C" int64_t nrf_mlp_bf16_packed_bytes(const nrf_net_t *net, const nrf_emb
     return bf_total_bytes(P);
 }
 
-extern "C" int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+static int pack_16bit_impl(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream, int f16) {
     NRF_REQUIRE(net && emb && packed, "nrf_mlp_bf16_pack_weights: null pointer");
     if (const char *e = bf_check_net(net, emb, false)) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_mlp_bf16_pack_weights: %s", e);
     NRF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nrf_mlp_bf16_pack_weights: packed must be 16-byte aligned");
     BfPlan P;
+    P.f16 = f16;
     bf_plan_net(P, net, emb, false);
     return bf_pack(P, packed, as_stream(stream));
 }
+extern "C" int nrf_mlp_bf16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    return pack_16bit_impl(net, emb, packed, stream, 0);
+}
+extern "C" int nrf_mlp_f16_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb, void *packed, void *stream) {
+    return pack_16bit_impl(net, emb, packed, stream, 1);
+}
 
-extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
-                                  const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
+static int query_fwd_16bit_impl(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream, bool f16) {
     NRF_REQUIRE(net && emb, "nrf_query_fwd_bf16: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "nrf_query_fwd_bf16: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_fwd_bf16: negative n_points");
@@ -1586,7 +1633,7 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
     const int64_t ntiles = (n_points + 255) / 256;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);   // 512 registers per lane: one workgroup per CU
     hipStream_t st = as_stream(stream);
-    switch (net->W / 32) {
+    switch ((net->W / 32) * (f16 ? -1 : 1)) {
         case 8:
             if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((query_fwd_bf16_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a);
@@ -1595,8 +1642,24 @@ extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, 
             if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((query_fwd_bf16_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a);
             break;
+        case -8:
+            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16_kernel<8, true, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((query_fwd_bf16_kernel<8, false, true>), dim3(blocks), dim3(256), 0, st, a);
+            break;
+        case -4:
+            if (a.use_viewdirs) hipLaunchKernelGGL((query_fwd_bf16_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((query_fwd_bf16_kernel<4, false, true>), dim3(blocks), dim3(256), 0, st, a);
+            break;
     }
-    return check_launch("nrf_query_fwd_bf16");
+    return check_launch(f16 ? "nrf_query_fwd_f16" : "nrf_query_fwd_bf16");
+}
+extern "C" int nrf_query_fwd_bf16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                  const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
+    return query_fwd_16bit_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, stream, false);
+}
+extern "C" int nrf_query_fwd_f16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                 const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, void *stream) {
+    return query_fwd_16bit_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, stream, true);
 }
 
 extern "C" int64_t nrf_mlp_bf16x3_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {

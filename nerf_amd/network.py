@@ -82,7 +82,8 @@ class NeRF(nn.Module):
         else:
             self.output_linear = nn.Linear(W, output_ch)
         self._packed_cache = {}
-        # "fp32" (exact f32 MFMA, the reference's arithmetic), "bf16" (bf16 MFMA, f32 accumulate) or "bf16x3" (every
+        # "fp32" (exact f32 MFMA, the reference's arithmetic), "bf16" (bf16 MFMA, f32 accumulate), "f16" (the same 16-bit
+        # kernel with f16 hidden operands, saturating at +-65504: 8x finer rounding at the same rate) or "bf16x3" (every
         # product as three bf16 MFMAs on hi/residual operands: f32-grade accuracy at ~3x the f32 kernel's rate); the
         # two bf16 modes serve inference through render()'s fused query only.  Not part of the reference's constructor:
         # set as an attribute.
@@ -99,8 +100,8 @@ class NeRF(nn.Module):
         if pk is None:
             params = self._pack_params()
             mode, L, Lv = key[:3]
-            if len(key) > 3 and key[3] in ("bf16", "bf16x3"):
-                cls = ops.PackedNetBf16 if key[3] == "bf16" else ops.PackedNetBf16x3
+            if len(key) > 3 and key[3] in ("bf16", "f16", "bf16x3"):
+                cls = {"bf16": ops.PackedNetBf16, "f16": ops.PackedNetF16, "bf16x3": ops.PackedNetBf16x3}[key[3]]
                 pk = cls(params, self.D, self.W, self.input_ch, self.input_ch_views, self.output_ch,
                          list(self.skips), self.use_viewdirs, multires=L, multires_views=Lv)
             else:
@@ -196,10 +197,10 @@ class NeRF(nn.Module):
             raise NotImplementedError("nerf_amd: gradients w.r.t. the view directions are not built (parameters and query "
                                       "points only); detach viewdirs")
         need_grad = self._need_grad(pts, input_grad_ok=True)      # d/d(pts): nrf_query_bwd_input
-        if self.precision in ("bf16", "bf16x3") and not need_grad:   # inference only; training stays exact f32
+        if self.precision in ("bf16", "f16", "bf16x3") and not need_grad:   # inference only; training stays exact f32
             key = key + (self.precision,)
-        elif self.precision not in ("fp32", "bf16", "bf16x3"):
-            raise ValueError(f"precision must be 'fp32', 'bf16' or 'bf16x3', not {self.precision!r}")
+        elif self.precision not in ("fp32", "bf16", "f16", "bf16x3"):
+            raise ValueError(f"precision must be 'fp32', 'bf16', 'f16' or 'bf16x3', not {self.precision!r}")
         return _QueryFunction.apply(self, key, pts, viewdirs if self.use_viewdirs else None, pts_per_ray,
                                     need_grad, *self._params_in_order())
 

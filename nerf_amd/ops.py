@@ -524,6 +524,7 @@ class PackedStraightNetBf16x3(PackedStraightNet):
 
 class PackedNetBf16(PackedNet):
     """bf16 weight stream of a NeRF module for nrf_query_fwd_bf16 (raw points + in-kernel encoding only)."""
+    _pack_fn, _query_fn = "nrf_mlp_bf16_pack_weights", "nrf_query_fwd_bf16"
 
     def __init__(self, params, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, multires=0,
                  multires_views=0):
@@ -550,8 +551,8 @@ class PackedNetBf16(PackedNet):
         dev = next(iter(self._p.values())).device
         if self.packed is None or self.packed.device != dev:
             self.packed = torch.empty((self.n_bytes,), device=dev, dtype=torch.uint8)
-        check(_lib.lib().nrf_mlp_bf16_pack_weights(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()),
-              "nrf_mlp_bf16_pack_weights")
+        check(getattr(_lib.lib(), self._pack_fn)(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _stream()),
+              self._pack_fn)
         self._versions = vers
 
     def query(self, pts, viewdirs=None, pts_per_ray=1):
@@ -561,13 +562,19 @@ class PackedNetBf16(PackedNet):
         raw = torch.empty((P, self.out_ch), device=pts.device, dtype=torch.float32)
         if viewdirs is not None:
             viewdirs = _f32(viewdirs, "viewdirs")
-        check(_lib.lib().nrf_query_fwd_bf16(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
-                                            _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _stream()),
-              "nrf_query_fwd_bf16")
+        check(getattr(_lib.lib(), self._query_fn)(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                                  _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _stream()),
+              self._query_fn)
         return raw
 
     def query_train(self, *a, **k):
         raise NotImplementedError("the bf16 path is inference only; training runs on the f32 kernels")
+
+
+class PackedNetF16(PackedNetBf16):
+    """The 16-bit variant with f16 hidden activations and weights (saturating at +-65504): nrf_query_fwd_f16.  Same rate as
+    bf16, 8x finer rounding; inference only."""
+    _pack_fn, _query_fn = "nrf_mlp_f16_pack_weights", "nrf_query_fwd_f16"
 
 
 class PackedNetBf16x3(PackedNetBf16):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every pixel of BASELINE configs[1] (800x800, 64+128 samples, D=8 W=256 coarse+fine) against the CPU oracle -- the
 checker of tests/, here run over the WHOLE image (640 000 rays, ~3 min of OpenMP on the GPU box's host cores; the test
-suite samples 1024 pixels).  Well-conditioned nets (fixture seeds 11 / 12); fp32, bf16x3 and bf16 kernels.  Writes
+suite samples 1024 pixels).  Well-conditioned nets (fixture seeds 11 / 12) and the bench's sharp nets; fp32, bf16x3, bf16 and f16 kernels.  Writes
 gpurun_out/<round>_fullsize_parity.json (copied to profiles/ by hand).
     python scripts/fullsize_parity.py [round-prefix] [static,dnerf,fern]
 dnerf: configs[4] at 400x400 (deformation chain, t = 0.5); fern: configs[3], the 1008x756 NDC view."""
@@ -54,7 +54,7 @@ def run(tag, seeds, peaky):
               network_fine=nets[1], N_samples=64, network_fn=nets[0], use_viewdirs=True, white_bkgd=True, raw_noise_std=0.,
               ndc=False, lindisp=False)
     c2w = torch.from_numpy(c2w_np).cuda()
-    for prec in ("fp32", "bf16x3", "bf16"):
+    for prec in ("fp32", "bf16x3", "bf16", "f16"):
         for n in nets:
             n.precision = prec
         with torch.no_grad():
@@ -71,7 +71,7 @@ def run(tag, seeds, peaky):
              "disp_max_abs": float(np.abs(disp - want["disp_map"]).max()),
              # rays whose last sample's sigma is within rounding of 0 flip alpha between 0 and 1 under any rounding (render.py:98)
              "rays_with_last_sigma_below_1e-4": int((last < 1e-4).sum())}
-        stable = last >= (2e-3 if prec == "bf16" else 1e-4)
+        stable = last >= {"bf16": 2e-3, "f16": 2.5e-4}.get(prec, 1e-4)
         e["rgb_max_abs_stable_rays"] = float(d[stable].max())
         e["stable_fraction"] = float(stable.mean())
         out[prec] = e

@@ -194,3 +194,89 @@ def test_bf16x3_meets_the_f32_bar(gold):
     np.testing.assert_allclose(host(ret["rgb0"]), gold["rr_smooth_rgb0"], atol=2e-4, rtol=0)
     psnr = -10 * np.log10(np.mean((host(ret["rgb_map"]) - gold["rr_smooth_rgb_map"]) ** 2) + 1e-30)
     assert psnr > 80.0, psnr
+
+
+# ------------------------------------------------------------------------------------------------ f16 variant (round 3)
+@pytest.mark.parametrize("peaky", [False, True])
+@pytest.mark.parametrize("n_points,ppr", [(64 * 7, 64), (256 * 5 + 192, 1), (65536 + 64, 64)])
+def test_f16_query_vs_f32_and_bf16(n_points, ppr, peaky):
+    """precision = "f16" (nrf_query_fwd_f16: hidden activations and weights in f16, saturating) against the exact f32
+    kernel: raw within 4e-3 of its scale -- 8x inside the bf16 bar of 3e-2 -- on the smooth and on the sharp (sigma head
+    x30) nets, deterministic, and closer to f32 than the bf16 kernel is."""
+    net = load_net(fx.make_nerf_state(24, peaky=peaky))
+    rng = np.random.RandomState(5)
+    pts = dev(rng.uniform(-2.5, 2.5, (n_points, 3)))
+    d = rng.normal(size=(n_points // ppr, 3))
+    dirs = dev(d / np.linalg.norm(d, axis=-1, keepdims=True))
+    with torch.no_grad():
+        ref = net.query_points(pts, dirs, ppr, 10, 4)
+        net.precision = "bf16"
+        b16 = net.query_points(pts, dirs, ppr, 10, 4)
+        net.precision = "f16"
+        out = net.query_points(pts, dirs, ppr, 10, 4)
+        out2 = net.query_points(pts, dirs, ppr, 10, 4)
+    assert torch.equal(out, out2) and torch.isfinite(out).all()
+    e16, eb = rel_err(host(out), host(ref)), rel_err(host(b16), host(ref))
+    print(f"f16 raw error {e16:.2e} of scale (bf16: {eb:.2e}), peaky={peaky}")
+    assert e16 < 4e-3, e16
+    assert e16 < 0.5 * eb, (e16, eb)
+
+
+def test_f16_small_noview_nets_and_saturation():
+    """W = 128 nets without / with view directions; then activations driven beyond f16's range (layer-0 weights x 1e5,
+    so a good part of the first hidden layer exceeds 65504 and the weights themselves do too): the saturating conversion
+    of activations and weights keeps every output finite, where an unclamped one would give inf and inf * 0 = NaN."""
+    rng = np.random.RandomState(6)
+    pts = dev(rng.uniform(-2, 2, (1000, 3)))
+    kw = dict(D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=[2], use_viewdirs=False)
+    sd = fx.make_nerf_state(23, D=4, W=128, input_ch=63, input_ch_views=0, output_ch=4, skips=(2,), use_viewdirs=False)
+    net = load_net(sd, **kw)
+    with torch.no_grad():
+        ref = net.query_points(pts, None, 1, 10, 0)
+        net.precision = "f16"
+        out = net.query_points(pts, None, 1, 10, 0)
+    assert rel_err(host(out), host(ref)) < 4e-3
+    kw = dict(D=3, W=128, input_ch=39, input_ch_views=15, output_ch=4, skips=[1], use_viewdirs=True)
+    sd = fx.make_nerf_state(26, D=3, W=128, input_ch=39, input_ch_views=15, output_ch=4, skips=(1,), use_viewdirs=True)
+    net = load_net(sd, **kw)
+    d = rng.normal(size=(10, 3))
+    dirs = dev(d / np.linalg.norm(d, axis=-1, keepdims=True))
+    with torch.no_grad():
+        ref = net.query_points(pts, dirs, 100, 6, 2)
+        net.precision = "f16"
+        out = net.query_points(pts, dirs, 100, 6, 2)
+    assert rel_err(host(out), host(ref)) < 4e-3
+    # saturation
+    sd = {k: v.copy() for k, v in fx.make_nerf_state(24).items()}
+    sd["pts_linears.0.weight"] *= 1.0e5
+    big = load_net(sd)
+    p2 = dev(rng.uniform(-2, 2, (512, 3)))
+    d2 = dev(fx.blender_rays(8, 2)[:, -3:])
+    with torch.no_grad():
+        ref = big.query_points(p2, d2, 64, 10, 4)
+        big.precision = "f16"
+        out = big.query_points(p2, d2, 64, 10, 4)
+    assert torch.isfinite(out).all() and torch.isfinite(ref).all()
+    from nerf_amd.positional_encoding import get_embedder
+    e10, _ = get_embedder(10, 0)
+    h0 = torch.relu(e10(p2) @ big.pts_linears[0].weight.T + big.pts_linears[0].bias)
+    assert float(h0.max()) > 65504.0 and float((h0 > 65504.0).float().mean()) > 0.05     # layer 0 does leave f16's range
+
+
+def test_f16_render_within_1e2(gold):
+    """End to end on the well-conditioned nets (the bf16 test's rays and exclusions): 2e-3 max-abs on rgb / acc."""
+    from nerf_amd.positional_encoding import get_embedder
+    from nerf_amd.render import render_rays, run_network
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    q = lambda i, v, f: run_network(i, v, f, e10, e4, 65536)  # noqa: E731
+    coarse, fine = load_net(fx.make_nerf_state(24)), load_net(fx.make_nerf_state(25))
+    coarse.precision = fine.precision = "f16"
+    with torch.no_grad():
+        ret = render_rays(dev(gold["rr_smooth_rays"]), coarse, q, 64, retraw=True, perturb=0., N_importance=128,
+                          network_fine=fine, white_bkgd=True)
+    stable = np.abs(gold["rr_smooth_raw"][:, -1, 3]) > 2e-3
+    for k in ("rgb_map", "acc_map"):
+        e = float(np.abs(host(ret[k])[stable] - gold[f"rr_smooth_{k}"][stable]).max())
+        print(f"f16 render {k}: {e:.2e}")
+        assert e <= 2e-3, (k, e)

@@ -50,7 +50,7 @@ def images(scene):
               network_fine=nets[1], N_samples=64, network_fn=nets[0], use_viewdirs=True, white_bkgd=True,
               raw_noise_std=0., ndc=False, lindisp=False)
     out = {}
-    for prec in ("fp32", "bf16x3", "bf16"):
+    for prec in ("fp32", "bf16x3", "bf16", "f16"):
         nets[0].precision = nets[1].precision = prec
         with torch.no_grad():
             rgb, disp, acc, _ = render(200, 200, scene["K"], chunk=32768, c2w=torch.from_numpy(scene["c2w"]).cuda(),
@@ -98,3 +98,20 @@ def test_bf16_psnr_delta(scene, images):
           f"{psnr(rgb, scene['rgb']):.1f} dB")
     assert abs(p_got - p_ref) <= 0.05, (p_got, p_ref)
     assert (d <= 1e-2).mean() >= 0.995, (d <= 1e-2).mean()
+
+
+def test_f16_psnr_delta(scene, images):
+    """The 16-bit kernel with f16 hidden operands: the north star's |PSNR delta| <= 0.05 dB, >= 99.8 % of the pixels within
+    1e-2 of the reference, and less than 0.6 x the bf16 kernel's 99th-percentile image error (measured: delta +0.019 dB --
+    like bf16's +0.021 it is carried by a handful of silhouette pixels where any rounding moves the resampling --, 99.87 %,
+    1.5e-3 vs 3.2e-3, PSNR between the images 58.7 vs 55.3 dB)."""
+    rgb, b16 = images["f16"][0], images["bf16"][0]
+    p_ref, p_got = psnr(scene["rgb"], scene["truth"]), psnr(rgb, scene["truth"])
+    d = np.abs(rgb - scene["rgb"]).max(-1)
+    print(f"trained scene f16: PSNR vs analytic {p_got:.4f} dB (reference {p_ref:.4f}), within 1e-2 of the reference "
+          f"{100 * (d <= 1e-2).mean():.3f} %, 99th percentile {np.percentile(d, 99):.2e}, PSNR between the images "
+          f"{psnr(rgb, scene['rgb']):.1f} dB (bf16: {psnr(b16, scene['rgb']):.1f} dB)")
+    assert abs(p_got - p_ref) <= 0.05, (p_got, p_ref)
+    assert (d <= 1e-2).mean() >= 0.998, (d <= 1e-2).mean()
+    assert np.percentile(d, 99) < 0.6 * np.percentile(np.abs(b16 - scene["rgb"]).max(-1), 99)
+    assert psnr(rgb, scene["rgb"]) > psnr(b16, scene["rgb"]) + 2.0
