@@ -115,25 +115,26 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
         if constexpr (GX) zero_acc<2>(gx);
         zero_acc<NT>(g);
         if (pl.use_viewdirs) {
-            if constexpr (NT >= 2) {
+            {
+                constexpr int NV = (NT + 1) / 2;     // tiles of the view layer (zero-padded when NT is odd)
                 float4 gr = live ? reinterpret_cast<const float4 *>(a.g_raw)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
                 float hv[8] = {gr.x, gr.y, gr.z, 0.f, 0.f, 0.f, 0.f, 0.f};
                 store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, hv, 3);          // d/d(rgb logits): rgb_linear wgrad
                 // through rgb_linear (network.py:64) and the view layer's ReLU
-                f32x16 g2[NT / 2];
-                zero_acc<NT / 2>(g2);
-                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 0 * (NT / 2) * 32, gr.x);
-                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NT / 2) * 32, gr.y);
-                axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NT / 2) * 32, gr.z);
-                apply_gate_bits<NT / 2>(load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane), g2);
+                f32x16 g2[NV];
+                zero_acc<NV>(g2);
+                axpy_head<NV>(g2, wb, (uint32_t)pl.rgb_vec + 0 * (NV) * 32, gr.x);
+                axpy_head<NV>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NV) * 32, gr.y);
+                axpy_head<NV>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NV) * 32, gr.z);
+                apply_gate_bits<NV>(load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane), g2);
                 // every gradient block is saved (for wgrad) by the GEMM that consumes it, four registers per k-group
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
                 {
                     uint32_t sec = (uint32_t)tl.g_hv;
                     asm volatile("" : "+s"(sec));
-                    const int voff = t8c_voff(tg, W / 2);
-                    gemm_hid_side<NT / 2, NT>(g, g2, wb, (uint32_t)pl.viewsT_w,
-                                              [&](int G) { store_acc_t8c_group<NT / 2>(tg, sec, voff, g2, G); });
+                    const int voff = t8c_voff(tg, 32 * NV);
+                    gemm_hid_side<NV, NT>(g, g2, wb, (uint32_t)pl.viewsT_w,
+                                              [&](int G) { store_acc_t8c_group<NV>(tg, sec, voff, g2, G); });
                 }
                 float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);       // d/d(alpha): alpha_linear wgrad
@@ -784,6 +785,16 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
         case 8: hipLaunchKernelGGL(dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, d); break;
         case 4: hipLaunchKernelGGL(dgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, d); break;
         case 2: hipLaunchKernelGGL(dgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 1: hipLaunchKernelGGL(dgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 3: hipLaunchKernelGGL(dgrad_kernel<3>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 5: hipLaunchKernelGGL(dgrad_kernel<5>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 6: hipLaunchKernelGGL(dgrad_kernel<6>, dim3(blocks), dim3(256), 0, st, d); break;
+        case 7: hipLaunchKernelGGL(dgrad_kernel<7>, dim3(blocks), dim3(256), 0, st, d); break;
+        case -1: hipLaunchKernelGGL((dgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        case -3: hipLaunchKernelGGL((dgrad_kernel<3, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        case -5: hipLaunchKernelGGL((dgrad_kernel<5, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        case -6: hipLaunchKernelGGL((dgrad_kernel<6, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        case -7: hipLaunchKernelGGL((dgrad_kernel<7, true>), dim3(blocks), dim3(256), 0, st, d); break;
         case -8: hipLaunchKernelGGL((dgrad_kernel<8, true>), dim3(blocks), dim3(256), 0, st, d); break;
         case -4: hipLaunchKernelGGL((dgrad_kernel<4, true>), dim3(blocks), dim3(256), 0, st, d); break;
         case -2: hipLaunchKernelGGL((dgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, d); break;
@@ -840,13 +851,14 @@ dgrad_done:
         Bwd::Dst fd[2] = {{0, W, grads->feature_w, grads->feature_b}, {W, 1, grads->alpha_w, grads->alpha_b}};
         rc = B.run(tl.g_feat, W + 32, nt + 1, &Hlast, 1, W, fd, 2);
         if (rc) return rc;
+        const int nv = (nt + 1) / 2;          // tiles of the view layer: W/2 live channels, zero-padded to 32 * nv
         Bwd::Dst vd{0, W / 2, grads->views_w, grads->views_b};
         Bwd::XPart vparts[2] = {{tl.a_feat, W, nt, BLK_HIDDEN, 0, 0, W, 0},
                                 {tl.a_din, 2 * kKsD, dk, pl.d_type, pl.d_param, kKsD, 0, W}};   // network.py:58: cat[feature, views]
-        rc = B.run(tl.g_hv, W / 2, nt / 2, vparts, 2, W + icv, &vd, 1);
+        rc = B.run(tl.g_hv, 32 * nv, nv, vparts, 2, W + icv, &vd, 1);
         if (rc) return rc;
         Bwd::Dst rd{0, 3, grads->rgb_w, grads->rgb_b};
-        Bwd::XPart hv{tl.a_hv, W / 2, nt / 2, BLK_HIDDEN, 0, 0, W / 2, 0};
+        Bwd::XPart hv{tl.a_hv, 32 * nv, nv, BLK_HIDDEN, 0, 0, W / 2, 0};
         rc = B.run(tl.g_head, 32, 1, &hv, 1, W / 2, &rd, 1);
         if (rc) return rc;
     } else {

@@ -54,7 +54,8 @@ static __global__ void __launch_bounds__(256) pack_kernel(PackArgs a, float *__r
             int per = s.nt_out * 32;
             int o = e / per, q = e - o * per;
             int i = q & 3, h = (q >> 2) & 1, g = (q >> 3) & 3, t = q >> 5;
-            v = s.src[(int64_t)o * s.ld + s.ch_off + 32 * t + 8 * g + 4 * h + i];
+            int c = 32 * t + 8 * g + 4 * h + i;          // n_src: live input channels (the last tile may be padding)
+            if (c < s.n_src) v = s.src[(int64_t)o * s.ld + s.ch_off + c];
         } else if (s.kind == 3) {
             v = s.src[e];
         }
@@ -101,10 +102,10 @@ struct Planner {
         return o;
     }
     void head(const float *w, const float *b, int ld, int n_out, int nt_in, int ch_off, int64_t &vec,
-              int64_t &bias_off) {
+              int64_t &bias_off, int n_in = -1) {
         int count = n_out * nt_in * 32;
         vec = alloc(count);
-        add(PackSec{w, vec, 2, ld, n_out, nt_in, 0, 0, 0, ch_off, count, 0, 0, 0});
+        add(PackSec{w, vec, 2, ld, n_out, nt_in, 0, 0, 0, ch_off, count, 0, n_in < 0 ? nt_in * 32 : n_in, 0});
         bias_off = alloc(n_out);
         add(PackSec{b, bias_off, 3, 0, n_out, 0, 0, 0, 0, 0, n_out, 0, 0, 0});
     }
@@ -145,7 +146,11 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     if (straight && __builtin_popcount((unsigned)net->skips_mask & ((1u << (D - 1)) - 1u)) > 1)
         return "the fused straightforward kernel takes one skip layer";
     pl.straight = straight;
-    if (views && (W / 2) % 32) return "use_viewdirs needs W/2 to be a multiple of 32";
+    // the view layer has W/2 outputs (network.py:40): nv whole tiles, the last one zero-padded when W/2 is not a multiple
+    // of 32 (W = 96, 160, 224; --netwidth accepts anything, config.py:20-27)
+    const int nv = (W / 2 + 31) / 32;
+    if (views && net->use_layernorm && (W / 2) % 32)
+        return "LayerNorm nets with view directions need W/2 to be a multiple of 32 (the statistics run over whole tiles)";
     pl.nt = W / 32;
     pl.n_trunk = D;
     pl.use_viewdirs = views;
@@ -208,10 +213,10 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
         P.head(net->alpha_w, net->alpha_b, W, 1, nt, 0, pl.alpha_vec, pl.alpha_b);                  // network.py:56
         pl.feat_w = P.gemm_block(net->feature_w, W, W, nt, BLK_HIDDEN, 0, 16 * nt, 0);               // network.py:57
         pl.feat_b = P.bias(net->feature_b, W, nt);
-        pl.views_w_hid = P.gemm_block(net->views_w, W + icv, W / 2, nt / 2, BLK_HIDDEN, 0, 16 * nt, 0);  // :58-62
-        pl.views_w_in = P.gemm_block(net->views_w, W + icv, W / 2, nt / 2, pl.d_type, pl.d_param, kKsD, W);
-        pl.views_b = P.bias(net->views_b, W / 2, nt / 2);
-        P.head(net->rgb_w, net->rgb_b, W / 2, 3, nt / 2, 0, pl.rgb_vec, pl.rgb_b);                   // network.py:64
+        pl.views_w_hid = P.gemm_block(net->views_w, W + icv, W / 2, nv, BLK_HIDDEN, 0, 16 * nt, 0);  // :58-62
+        pl.views_w_in = P.gemm_block(net->views_w, W + icv, W / 2, nv, pl.d_type, pl.d_param, kKsD, W);
+        pl.views_b = P.bias(net->views_b, W / 2, nv);
+        P.head(net->rgb_w, net->rgb_b, W / 2, 3, nv, 0, pl.rgb_vec, pl.rgb_b, W / 2);                // network.py:64
     } else {
         P.head(net->out_w, net->out_b, W, pl.output_ch, nt, 0, pl.out_vec, pl.out_b);               // network.py:67
     }
@@ -225,8 +230,8 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
         }
         if (views) {
             pl.views_ln = P.cur;
-            P.bias(net->views_ln_w, W / 2, nt / 2);
-            P.bias(net->views_ln_b, W / 2, nt / 2);
+            P.bias(net->views_ln_w, W / 2, nv);
+            P.bias(net->views_ln_b, W / 2, nv);
         }
     }
     // W^T blocks for the backward chain (dgrad): hidden parts only (inputs need no gradient here)
@@ -238,7 +243,7 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     }
     if (views) {
         pl.featT_w = P.gemm_block_T(net->feature_w, W, 0, W, nt, W, nt);
-        pl.viewsT_w = P.gemm_block_T(net->views_w, W + icv, 0, W, nt, W / 2, nt / 2);
+        pl.viewsT_w = P.gemm_block_T(net->views_w, W + icv, 0, W, nt, W / 2, nv);
     }
     // W_x^T blocks (gradient w.r.t. the encoded position, needed when the points themselves depend on parameters:
     // the D-NeRF chain x + dx).  Canonical nets with the fused encoding only.

@@ -131,22 +131,23 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
             for (int l = 1; l < pl.n_trunk; ++l) trunk_layer(l, std::false_type{});
         }
         if (pl.use_viewdirs) {
-            if constexpr (NT >= 2) {
+            {
+                constexpr int NV = (NT + 1) / 2;     // tiles of the view layer (W/2 outputs; zero-padded when NT is odd)
                 const float alpha = head_dot<NT>(hin, wb, (uint32_t)pl.alpha_vec) + wload1(wb, (uint32_t)pl.alpha_b * 4);
                 // network.py:57 -- feature_linear's bias is already in acc (fetched by the last trunk move)
                 if constexpr (TRAIN) gemm_hid_side<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w, save_hin(pl.n_trunk - 1));
                 else gemm_hid<NT, NT>(acc, hin, wb, (uint32_t)pl.feat_w);
                 // the feature vector becomes an MFMA operand: move it out of the accumulator file (no ReLU)
                 relu_move<NT>(hin, acc, false);
-                f32x16 acc2[NT / 2];
-                load_bias<NT / 2>(acc2, wb, (uint32_t)pl.views_b);                               // network.py:58-62
+                f32x16 acc2[NV];
+                load_bias<NV>(acc2, wb, (uint32_t)pl.views_b);                               // network.py:58-62
                 if constexpr (TRAIN) {
                     uint32_t sec = (uint32_t)a.tl.a_feat;
                     asm volatile("" : "+s"(sec));
-                    gemm_hid_side<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid,
+                    gemm_hid_side<NT, NV>(acc2, hin, wb, (uint32_t)pl.views_w_hid,
                                               [&](int G) { store_acc_t8_group<NT>(tb, sec, hin, G); });
                 } else {
-                    gemm_hid<NT, NT / 2>(acc2, hin, wb, (uint32_t)pl.views_w_hid);
+                    gemm_hid<NT, NV>(acc2, hin, wb, (uint32_t)pl.views_w_hid);
                 }
                 // the direction encoding is built here, not at the top: 16 registers the trunk cannot spare
                 float din[kKsD];
@@ -157,18 +158,18 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                     fill_pe3<kKsD>(din, d[0], d[1], d[2], pl.d_param, h);
                 }
                 if constexpr (TRAIN) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
-                gemm_in<kKsD, NT / 2>(acc2, din, wb, (uint32_t)pl.views_w_in);
-                if constexpr (LN) ln_relu_move<NT / 2>(acc2, acc2, wb, (uint32_t)pl.views_ln);       // network.py:88-90
-                else relu_move<NT / 2>(acc2, acc2, true);
+                gemm_in<kKsD, NV>(acc2, din, wb, (uint32_t)pl.views_w_in);
+                if constexpr (LN) ln_relu_move<NV>(acc2, acc2, wb, (uint32_t)pl.views_ln);       // network.py:88-90
+                else relu_move<NV>(acc2, acc2, true);
                 if constexpr (TRAIN) {
-                    store_acc_t8<NT / 2>(tb, (uint32_t)a.tl.a_hv, acc2);
-                    store_gate_bits<NT / 2>(tb, (uint32_t)a.tl.a_mask + pl.n_trunk * 256, acc2, lane);
+                    store_acc_t8<NV>(tb, (uint32_t)a.tl.a_hv, acc2);
+                    store_gate_bits<NV>(tb, (uint32_t)a.tl.a_mask + pl.n_trunk * 256, acc2, lane);
                 }
                 const uint32_t rv = (uint32_t)pl.rgb_vec, rb = (uint32_t)pl.rgb_b * 4;
                 float4 o;                                                                        // network.py:64-65
-                o.x = head_dot<NT / 2>(acc2, wb, rv + 0 * (NT / 2) * 32) + wload1(wb, rb + 0);
-                o.y = head_dot<NT / 2>(acc2, wb, rv + 1 * (NT / 2) * 32) + wload1(wb, rb + 4);
-                o.z = head_dot<NT / 2>(acc2, wb, rv + 2 * (NT / 2) * 32) + wload1(wb, rb + 8);
+                o.x = head_dot<NV>(acc2, wb, rv + 0 * (NV) * 32) + wload1(wb, rb + 0);
+                o.y = head_dot<NV>(acc2, wb, rv + 1 * (NV) * 32) + wload1(wb, rb + 4);
+                o.z = head_dot<NV>(acc2, wb, rv + 2 * (NV) * 32) + wload1(wb, rb + 8);
                 o.w = alpha;
                 if (h == 0 && p < a.n_points) reinterpret_cast<float4 *>(a.raw)[p] = o;
             }
@@ -217,6 +218,23 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
             return check_launch("nrf_dnerf_time_fwd_train");
         }
     }
+    if (a.acts)
+        hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, true>), dim3(blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false>), dim3(blocks), dim3(256), 0, st, a);
+    return check_launch("nrf_query_fwd");
+}
+
+// Widths other than 64 / 128 / 256: the static NeRF's kernels (inference and training forward); the D-NeRF time /
+// straightforward variants and the LayerNorm instantiations are built for the three shipped widths only.
+template <int NT, bool EMB>
+static int launch_query_plain(const QueryArgs &a, hipStream_t st) {
+    if (a.plan.straight || a.plan.layernorm || a.times)
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d: the D-NeRF time / straightforward and LayerNorm kernels are "
+                         "built for W = 64, 128, 256", NT * 32);
+    int64_t ntiles = (a.n_points + 31) / 32;
+    int blocks = (int)((ntiles + 3) / 4);
+    if (blocks > 256) blocks = 256;
     if (a.acts)
         hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, true>), dim3(blocks), dim3(256), 0, st, a);
     else
@@ -280,8 +298,14 @@ static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const fl
         case 8: return emb1 ? launch_query<8, true>(a, st) : launch_query<8, false>(a, st);
         case 4: return emb1 ? launch_query<4, true>(a, st) : launch_query<4, false>(a, st);
         case 2: return emb1 ? launch_query<2, true>(a, st) : launch_query<2, false>(a, st);
+        // every other --netwidth that is a multiple of 32 (config.py:20-27 accepts any): the plain NeRF kernels
+        case 1: return emb1 ? launch_query_plain<1, true>(a, st) : launch_query_plain<1, false>(a, st);
+        case 3: return emb1 ? launch_query_plain<3, true>(a, st) : launch_query_plain<3, false>(a, st);
+        case 5: return emb1 ? launch_query_plain<5, true>(a, st) : launch_query_plain<5, false>(a, st);
+        case 6: return emb1 ? launch_query_plain<6, true>(a, st) : launch_query_plain<6, false>(a, st);
+        case 7: return emb1 ? launch_query_plain<7, true>(a, st) : launch_query_plain<7, false>(a, st);
         default:
-            return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d has no fused kernel (64, 128, 256 do)", net->W);
+            return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d has no fused kernel (multiples of 32 up to 256 do)", net->W);
     }
 }
 

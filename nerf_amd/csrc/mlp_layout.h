@@ -112,13 +112,13 @@ struct TrainLayout {
     // activations (floats from the tile's base)
     int64_t a_xin, a_din, a_tin;     // input blocks in k-step space: channel 2*step + half (64 / 32 / 24 ch)
     int64_t a_trunk;                 // D sections of W channels: post-ReLU outputs of trunk layer l
-    int64_t a_feat, a_hv;            // feature_linear output (W), views layer output (W/2, post-ReLU)
+    int64_t a_feat, a_hv;            // feature_linear output (W), views layer output (W/2 padded to whole tiles, post-ReLU)
     int64_t a_mask;                  // ReLU gates as bits: D + 1 slots (trunk layers, view layer) of [64 lanes][4 dwords]
     int64_t a_tile;                  // floats per tile
     // gradients w.r.t. pre-activations
     int64_t g_trunk;                 // D sections of W
     int64_t g_feat;                  // W + 32: the extra tile's row 0 is d/d(alpha)
-    int64_t g_hv;                    // W/2
+    int64_t g_hv;                    // W/2 padded to whole tiles
     int64_t g_head;                  // 32: rows 0..2 d/d(rgb)  (or d/d(output_linear out) rows 0..output_ch-1)
     int64_t g_xin;                   // 64: d/d(gamma(x)) in the reference's channel order (only written on request)
     int64_t g_tile;
@@ -128,19 +128,20 @@ NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
     TrainLayout t{};
     t.nt = nt; t.n_trunk = D; t.use_viewdirs = use_viewdirs;
     const int W = 32 * nt;
+    const int Wv = 32 * ((nt + 1) / 2);     // the view layer's W/2 outputs in whole 32-channel tiles (W = 96: 48 -> 64, zero-padded)
     int64_t c = 0;
     t.a_xin = c; c += 32 * 2 * kKsX;
     t.a_din = c; c += 32 * 2 * kKsD;
     t.a_tin = c; c += 32 * 2 * kKsT;
     t.a_trunk = c; c += (int64_t)32 * W * D;
     t.a_feat = c; c += 32 * W;
-    t.a_hv = c; c += 32 * (W / 2);
+    t.a_hv = c; c += 32 * Wv;
     t.a_mask = c; c += (int64_t)256 * (D + 1);
     t.a_tile = c;
     c = 0;
     t.g_trunk = c; c += (int64_t)32 * W * D;
     t.g_feat = c; c += 32 * (W + 32);
-    t.g_hv = c; c += 32 * (W / 2);
+    t.g_hv = c; c += 32 * Wv;
     t.g_head = c; c += 32 * 32;
     t.g_xin = c; c += 32 * 64;
     t.g_tile = c;

@@ -15,6 +15,10 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
+def host(t):
+    return t.detach().cpu().numpy()
+
+
 def _case(seed):
     rng = np.random.RandomState(1000 + seed)
     D = int(rng.randint(2, 9))
@@ -57,6 +61,74 @@ def test_random_net_query_all_precisions(seed):
             with torch.no_grad():
                 g2 = q().cpu().numpy()
             assert np.abs(g2 - want).max() <= bar * scale, (prec, cfg, n_rays, S, np.abs(g2 - want).max() / scale)
+
+
+@pytest.mark.parametrize("views", [True, False])
+@pytest.mark.parametrize("W", [32, 96, 160, 192, 224])
+def test_every_width_that_is_a_multiple_of_32(W, views):
+    """--netwidth takes any value (config.py:20-27); every multiple of 32 up to 256 runs on the fused f32 kernels -- the
+    view layer's W/2 outputs in whole tiles, zero-padded when W/2 is not a multiple of 32 (W = 96, 160, 224): the query on
+    raw points and on embedded rows against the oracle (2e-5 of scale), every parameter gradient against float64 autograd
+    (2e-3 of its scale), bitwise repeatable, and NeRF._composed (the GPU torch composition) is never reached."""
+    from nerf_amd.network import NeRF
+    rng = np.random.RandomState(W + views)
+    D, L, Lv = 5, 10, 4
+    cfg = dict(D=D, W=W, input_ch=3 + 6 * L, input_ch_views=(3 + 6 * Lv) if views else 0, output_ch=4, skips=(2,),
+               use_viewdirs=views)
+    sd = fx.make_nerf_state(800 + W, **cfg)
+    net = NeRF(D=D, W=W, input_ch=cfg["input_ch"], input_ch_views=cfg["input_ch_views"], output_ch=4, skips=[2],
+               use_viewdirs=views)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if k in net.state_dict()}, strict=False)
+    net = net.cuda()
+    assert net.kernel_shape_reason() is None
+    net._composed = None                       # reaching the composition would raise
+    n_rays, S = 23, 37                         # 851 points: ragged tiles
+    pts = rng.uniform(-2.5, 2.5, (n_rays, S, 3)).astype(np.float32)
+    d = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    full = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want = orc.run_network(pts, d if views else None, orc.Net(full, **cfg), L, Lv).reshape(n_rays * S, -1)
+    scale = max(np.abs(want).max(), 1e-6)
+    P, dirs = dev(pts.reshape(-1, 3)), dev(d)
+    with torch.no_grad():
+        got = net.query_points(P, dirs if views else None, S, L, Lv)
+        # the same through forward() on embedded rows (embed mode 1: what the generic run_network route calls)
+        from nerf_amd.positional_encoding import get_embedder
+        e, _ = get_embedder(L, 0)
+        rows = e(P)
+        if views:
+            ev, _ = get_embedder(Lv, 0)
+            rows = torch.cat([rows, ev(dirs.repeat_interleave(S, 0))], -1)
+        got_rows = net(rows)
+    assert np.abs(host(got) - want).max() <= 2e-5 * scale, np.abs(host(got) - want).max() / scale
+    assert np.abs(host(got_rows) - want).max() <= 2e-5 * scale
+    # training: forward with saved activations, dgrad, wgrad, reduction
+    out = net.query_points(P, dirs if views else None, S, L, Lv)
+    assert np.abs(host(out) - want).max() <= 2e-5 * scale
+    g = dev(rng.normal(size=tuple(out.shape)))
+    (out * g).sum().backward()
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in net.state_dict(keep_vars=True).items()}
+    ref = _torch_forward64(sd64, cfg, P.double(), L, Lv, dirs.double().repeat_interleave(S, 0))
+    (ref * g.double()).sum().backward()
+    used = [k for k in sd64 if views or not k.startswith("views_linears")]
+    params = dict(net.named_parameters())
+    for k in used:
+        gw, ww = params[k].grad, sd64[k].grad
+        assert gw is not None and gw.shape == ww.shape, k
+        err = float((gw.double() - ww).abs().max()) / (float(ww.abs().max()) + 1e-30)
+        assert err < 2e-3, (k, W, err)
+    first = {k: params[k].grad.clone() for k in used}
+    net.zero_grad()
+    (net.query_points(P, dirs if views else None, S, L, Lv) * g).sum().backward()
+    assert all(torch.equal(first[k], params[k].grad) for k in used)
+    # gradients w.r.t. the query points (nrf_query_bwd_input: the GX instantiation of the dgrad chain)
+    Pg = P.clone().requires_grad_(True)
+    (net.query_points(Pg, dirs if views else None, S, L, Lv) * g).sum().backward()
+    P64 = P.double().requires_grad_(True)
+    sd64b = {k: v.detach().double() for k, v in net.state_dict().items()}
+    (_torch_forward64(sd64b, cfg, P64, L, Lv, dirs.double().repeat_interleave(S, 0)) * g.double()).sum().backward()
+    err = float((Pg.grad.double() - P64.grad).norm() / P64.grad.norm())
+    assert err < 1e-3, err
 
 
 @pytest.mark.parametrize("seed", range(8))
