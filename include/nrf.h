@@ -26,7 +26,7 @@ extern "C" {
 
 /* bumped whenever a struct layout or a signature changes (200: nrf_net_t carries the LayerNorm parameters); a binding
  * compares nrf_version() with the NRF_VERSION it was written against before passing structs */
-#define NRF_VERSION 210
+#define NRF_VERSION 220
 #define NRF_MAX_D 16
 
 typedef enum {
@@ -50,7 +50,10 @@ typedef struct {
     const float *out_w, *out_b; /* output_linear (use_viewdirs == 0) */
     /* LayerNorm variant (vanilla_dynamic/network.py:46-48, :75-76, :88-89, :276-300): nn.LayerNorm(W) after every trunk
      * Linear (weight / bias of pts_layernorms[i], or of _time_layernorms[i] for a time-net descriptor) and nn.LayerNorm(W/2)
-     * after the view layer.  use_layernorm == 0: the pointers are ignored.  Forward (inference) only; eps = 1e-5. */
+     * after the view layer.  use_layernorm == 0: the pointers are ignored.  eps = 1e-5.  Inference and (220) training in f32 for
+     * W = 64, 128, 256: nrf_query_fwd_train saves the normalised values, nrf_query_bwd / nrf_query_bwd_input / nrf_dnerf_time_bwd
+     * run the LayerNorm backward inside the dgrad chain and write the affine parameters' gradients through the same fields of
+     * `grads`. */
     int32_t use_layernorm, reserved2;
     const float *ln_w[NRF_MAX_D];
     const float *ln_b[NRF_MAX_D];

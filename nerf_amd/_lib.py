@@ -30,7 +30,7 @@ class NrfEmbed(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 210     # include/nrf.h NRF_VERSION
+ABI_VERSION = 220     # include/nrf.h NRF_VERSION
 
 _SIGS = {
     "nrf_version": (C.c_int, []),

@@ -76,6 +76,64 @@ __device__ __forceinline__ void relu_mask_t8(const TBuf &ta, uint32_t sec, f32x1
     }
 }
 
+// LayerNorm backward in registers (autograd of vanilla_dynamic/network.py:75-76 / :88-89 / :298-299): on entry g holds
+// d/d(LayerNorm output) of this lane's channels (already through the ReLU gate); on exit d/d(Linear output):
+//     a = g * gamma;   g_z = rstd * (a - mean_c(a) - xhat * mean_c(a * xhat))
+// with xhat = (z - mean) * rstd and rstd as the training forward saved them.  The incoming g is also written to `gy_sec`
+// of the gradient workspace: with xhat it gives the affine parameters' gradients (ln_param_grad_kernel).
+// Two passes over the tile's saved xhat (the second re-read hits in L2); a lane holds 16 * NT of its point's channels,
+// lane ^ 32 the rest, so both channel means are lane-local sums finished by one cross-half shuffle.
+template <int NT>
+__device__ __forceinline__ void ln_bwd(f32x16 (&g)[NT], const TBuf &ta, const TBuf &tg, const WBuf &wb, uint32_t xhat_sec,
+                                       uint32_t rstd_off, uint32_t gamma, uint32_t gy_sec) {
+    constexpr int C = 32 * NT;
+    constexpr float inv_n = 1.0f / C;
+    const int voff = ((ta.m * C + 4 * ta.h) * 8 + ta.q7) * 4;
+    asm volatile("" : "+s"(xhat_sec), "+s"(rstd_off), "+s"(gamma), "+s"(gy_sec));
+    const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ta.rsrc, (ta.m * 8 + ta.q7) * 4,
+                                                                                      (int)(rstd_off * 4), 0));
+    float s1 = 0.0f, s2 = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float xh[16];
+        f32x4 w[4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            xh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                ta.rsrc, voff, (int)((xhat_sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wload(wb, wb.h16, (gamma + ((t * 4 + q) * 2) * 4) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g[t][r]), tg.rsrc, voff,
+                                                  (int)((gy_sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = g[t][r] * w[r >> 2][r & 3];
+            g[t][r] = a;
+            s1 += a;
+            s2 = fmaf(a, xh[r], s2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    s1 = (s1 + __shfl_xor(s1, 32)) * inv_n;
+    s2 = (s2 + __shfl_xor(s2, 32)) * inv_n;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float xh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            xh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                ta.rsrc, voff, (int)((xhat_sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = rstd * ((g[t][r] - s1) - xh[r] * s2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
                     const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
                     hipStream_t st);      // mlp_bf16.hip
@@ -90,7 +148,9 @@ struct DgradArgs {
     int64_t n_points;
 };
 
-template <int NT, bool GX = false>
+// LN: the use_layernorm nets -- every gated gradient passes through the LayerNorm backward (ln_bwd) on its way to the
+// Linear's output, where the chain and the weight-gradient GEMMs take it as before
+template <int NT, bool GX = false, bool LN = false>
 __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
     const NetPlan &pl = a.plan;
     const TrainLayout &tl = a.tl;
@@ -127,6 +187,9 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
                 axpy_head<NV>(g2, wb, (uint32_t)pl.rgb_vec + 1 * (NV) * 32, gr.y);
                 axpy_head<NV>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NV) * 32, gr.z);
                 apply_gate_bits<NV>(load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane), g2);
+                if constexpr (LN)
+                    ln_bwd<NV>(g2, ta, tg, wb, (uint32_t)tl.a_xhat_v, (uint32_t)tl.a_rstd + pl.n_trunk * 32,
+                               (uint32_t)pl.views_ln, (uint32_t)tl.g_ln_v);
                 // every gradient block is saved (for wgrad) by the GEMM that consumes it, four registers per k-group
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
                 {
@@ -162,6 +225,11 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
         // trunk in reverse (network.py:49-53)
         u32x4 gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (pl.n_trunk - 1) * 256, lane);
         apply_gate_bits<NT>(gate, g);
+        auto ln_layer = [&](int l) {
+            ln_bwd<NT>(g, ta, tg, wb, (uint32_t)tl.a_xhat + l * (32 * W), (uint32_t)tl.a_rstd + l * 32,
+                       (uint32_t)(pl.ln_base + (int64_t)l * pl.ln_stride), (uint32_t)tl.g_ln + l * (32 * W));
+        };
+        if constexpr (LN) ln_layer(pl.n_trunk - 1);
         for (int l = pl.n_trunk - 1; l >= 0; --l) {
             // g = gated gradient w.r.t. layer l's pre-activations; the next layer's gates are in flight during this GEMM
             if (l > 0) gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);
@@ -179,6 +247,7 @@ __global__ void __launch_bounds__(256, 1) dgrad_kernel(const DgradArgs a) {
                 gemm_hid_side<NT, NT>(nx, g, wb, (uint32_t)(pl.trunkT_base + (int64_t)(l - 1) * pl.trunkT_stride),
                                       [&](int G) { store_acc_t8c_group<NT>(tg, sec, voff, g, G); });
                 move_gated<NT>(g, nx, gate);     // through layer l-1's ReLU, on the way out of the accumulators
+                if constexpr (LN) ln_layer(l - 1);
             } else {
                 store_acc_t8c<NT>(tg, (uint32_t)tl.g_trunk, W, g);      // layer 0's block has no consumer
             }
@@ -621,6 +690,62 @@ __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceBatch ba
     }
 }
 
+// ---- gradients of the LayerNorm affine parameters (vanilla_dynamic/network.py:46-48, :275-277):
+//   d(weight)[c] = sum_points g_y[c, p] * xhat[c, p],   d(bias)[c] = sum_points g_y[c, p]
+// from the T8 sections the dgrad chain (g_y) and the training forward (xhat) wrote.  HBM-bound (8 B per channel and point),
+// two stages with fixed summation orders (bit-reproducible): a block = (chunk of tiles, layer), thread = channel -- for a
+// fixed channel a tile holds 4 runs of 8 points, and neighbouring threads read neighbouring 32-byte runs.
+constexpr int kLnEntries = NRF_MAX_D + 1;     // trunk layers + the view layer
+constexpr int kLnChunks = 64;
+struct LnGradEntry {
+    int64_t g_sec, a_sec;
+    int32_t C, n_valid;
+    float *dst_w, *dst_b;
+};
+struct LnGradArgs {
+    const float *gbuf, *acts;
+    float *partial;          // [entry][chunk][2][256]
+    int64_t g_tile, a_tile, ntiles;
+    int32_t chunk_tiles, nchunks;
+    LnGradEntry e[kLnEntries];
+};
+
+__global__ void __launch_bounds__(256) ln_param_grad_kernel(const LnGradArgs a) {
+    const LnGradEntry &e = a.e[blockIdx.y];
+    const int c = threadIdx.x, chunk = blockIdx.x;
+    float sw = 0.0f, sb = 0.0f;
+    if (c < e.C) {
+        const int64_t t0 = (int64_t)chunk * a.chunk_tiles, t1 = min(a.ntiles, t0 + a.chunk_tiles);
+        for (int64_t tile = t0; tile < t1; ++tile) {
+            const float *g = a.gbuf + tile * a.g_tile + e.g_sec + c * 8;
+            const float *x = a.acts + tile * a.a_tile + e.a_sec + c * 8;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4 *>(g + m * e.C * 8), g1 = *reinterpret_cast<const f32x4 *>(g + m * e.C * 8 + 4);
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(x + m * e.C * 8), x1 = *reinterpret_cast<const f32x4 *>(x + m * e.C * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sb += g0[i]; sw = fmaf(g0[i], x0[i], sw); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sb += g1[i]; sw = fmaf(g1[i], x1[i], sw); }
+            }
+        }
+    }
+    float *out = a.partial + ((int64_t)blockIdx.y * a.nchunks + chunk) * 512;
+    out[c] = sw;
+    out[256 + c] = sb;
+}
+
+__global__ void __launch_bounds__(256) ln_param_reduce_kernel(const LnGradArgs a) {
+    const LnGradEntry &e = a.e[blockIdx.x];
+    const int c = threadIdx.x;
+    if (c >= e.n_valid) return;
+    const float *in = a.partial + (int64_t)blockIdx.x * a.nchunks * 512;
+    float sw = 0.0f, sb = 0.0f;
+    for (int k = 0; k < a.nchunks; ++k) { sw += in[k * 512 + c]; sb += in[k * 512 + 256 + c]; }
+    e.dst_w[c] = sw;
+    e.dst_b[c] = sb;
+}
+
 struct Bwd {
     const nrf_net_t *net;
     const nrf_net_t *grads;
@@ -729,8 +854,13 @@ static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles, int max_chunks = 25
 
 extern "C" int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points) {
     if (!net || net->W % 32 || n_points < 0) return -1;
-    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, net->use_layernorm);
     return ((n_points + 31) / 32) * tl.g_tile;
+}
+
+// LayerNorm nets: the partial sums of ln_param_grad_kernel live behind the weight-gradient slabs
+static int64_t ln_partial_floats(const nrf_net_t *net) {
+    return net->use_layernorm ? (int64_t)kLnEntries * kLnChunks * 512 : 0;
 }
 
 static int64_t slab_floats(const nrf_net_t *net, int64_t n_points, int max_chunks) {
@@ -740,7 +870,7 @@ static int64_t slab_floats(const nrf_net_t *net, int64_t n_points, int max_chunk
     // every GEMM of the pass (<= D trunk layers + 3 heads) keeps its own slab region; bound on each:
     // (feature + alpha row) x cat[hidden, gamma(x), gamma(t)]
     int64_t np = net->W + 32, kp = net->W + 2 * kKsX + 32;
-    return nchunks * (net->D + 3) * (np * kp + np);
+    return nchunks * (net->D + 3) * (np * kp + np) + ln_partial_floats(net);
 }
 
 extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points) { return slab_floats(net, n_points, 256); }
@@ -757,7 +887,8 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     Planner P{};
     const char *e = plan_net(P, net, emb, time_ch, straight);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: %s", e);
-    if (P.plan.layernorm) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: LayerNorm nets have no fused backward");
+    if (P.plan.layernorm && (x3 || straight || (P.plan.nt != 2 && P.plan.nt != 4 && P.plan.nt != 8)))
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: the LayerNorm backward is built in f32 for W = 64, 128, 256");
     if (n_points == 0) return NRF_OK;
     const bool want_gx = g_pts != nullptr;
     if (want_gx) {
@@ -769,7 +900,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     const int nt = pl.nt, W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
     hipStream_t st = as_stream(stream);
     DgradArgs d{};
-    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs);
+    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs, pl.layernorm);
     d.packed = packed; d.g_raw = g_raw; d.acts = acts; d.gbuf = gbuf; d.n_points = n_points;
     const int64_t ntiles = (n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
@@ -781,6 +912,17 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
         x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st);
     if (x3rc != NRF_OK && x3rc != NRF_ERR_UNSUPPORTED) return x3rc;
     if (x3rc == NRF_OK) goto dgrad_done;
+    if (pl.layernorm) {
+        switch (want_gx ? -nt : nt) {
+            case 8: hipLaunchKernelGGL((dgrad_kernel<8, false, true>), dim3(blocks), dim3(256), 0, st, d); break;
+            case 4: hipLaunchKernelGGL((dgrad_kernel<4, false, true>), dim3(blocks), dim3(256), 0, st, d); break;
+            case 2: hipLaunchKernelGGL((dgrad_kernel<2, false, true>), dim3(blocks), dim3(256), 0, st, d); break;
+            case -8: hipLaunchKernelGGL((dgrad_kernel<8, true, true>), dim3(blocks), dim3(256), 0, st, d); break;
+            case -4: hipLaunchKernelGGL((dgrad_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, d); break;
+            default: hipLaunchKernelGGL((dgrad_kernel<2, true, true>), dim3(blocks), dim3(256), 0, st, d); break;
+        }
+        goto dgrad_done;
+    }
     switch (want_gx ? -nt : nt) {
         case 8: hipLaunchKernelGGL(dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, d); break;
         case 4: hipLaunchKernelGGL(dgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, d); break;
@@ -814,7 +956,30 @@ dgrad_done:
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
     B.ntiles = ntiles; B.st = st; B.x3 = x3;
     B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, max_chunks);
-    B.slab_cap = slab_floats(net, n_points, max_chunks);
+    B.slab_cap = slab_floats(net, n_points, max_chunks) - ln_partial_floats(net);
+    if (pl.layernorm) {   // the affine parameters' gradients: independent of the weight-gradient GEMMs below
+        LnGradArgs la{};
+        la.gbuf = gbuf; la.acts = acts; la.partial = slab + B.slab_cap;
+        la.g_tile = d.tl.g_tile; la.a_tile = d.tl.a_tile; la.ntiles = ntiles;
+        la.nchunks = (int)std::min<int64_t>(ntiles, kLnChunks);
+        la.chunk_tiles = (int)((ntiles + la.nchunks - 1) / la.nchunks);
+        la.nchunks = (int)((ntiles + la.chunk_tiles - 1) / la.chunk_tiles);
+        int ne = 0;
+        for (int l = 0; l < D; ++l) {
+            NRF_REQUIRE(grads->ln_w[l] && grads->ln_b[l], "nrf_query_bwd: grads->ln_w/ln_b[%d] is null", l);
+            la.e[ne++] = LnGradEntry{d.tl.g_ln + (int64_t)l * 32 * W, d.tl.a_xhat + (int64_t)l * 32 * W, W, W,
+                                     const_cast<float *>(grads->ln_w[l]), const_cast<float *>(grads->ln_b[l])};
+        }
+        if (pl.use_viewdirs) {
+            NRF_REQUIRE(grads->views_ln_w && grads->views_ln_b, "nrf_query_bwd: grads->views_ln_w/views_ln_b is null");
+            la.e[ne++] = LnGradEntry{d.tl.g_ln_v, d.tl.a_xhat_v, W / 2, W / 2, const_cast<float *>(grads->views_ln_w),
+                                     const_cast<float *>(grads->views_ln_b)};
+        }
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3(la.nchunks, ne), dim3(256), 0, st, la);
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ne), dim3(256), 0, st, la);
+        rc = check_launch("nrf_query_bwd (LayerNorm parameter gradients)");
+        if (rc) return rc;
+    }
     const TrainLayout &tl = d.tl;
     const int xk = 2 * kKsX / 32, dk = 2 * kKsD / 32;  // 32-channel tiles of the k-space input blocks
     const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};

@@ -371,42 +371,12 @@ __device__ __forceinline__ void relu_move(f32x16 (&dst)[NT], const f32x16 (&src)
 // 75-77): a lane holds 16 * NT of its point's channels, lane ^ 32 the others, so the two row statistics (mean, then the
 // centred variance: biased, eps = 1e-5, as nn.LayerNorm) are lane-local sums finished by one cross-half shuffle each.
 // `ln` = offset of (weight, bias) in bias order.  dst may alias src.
-template <int NT>
-__device__ __forceinline__ void ln_relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], const WBuf &wb, uint32_t ln) {
-    constexpr float inv_n = 1.0f / (32 * NT);
-    asm volatile("" : "+s"(ln));
-    float s = 0.0f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += src[t][r];
-    const float mean = (s + __shfl_xor(s, 32)) * inv_n;
-    float v = 0.0f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = src[t][r] - mean;
-            v = fmaf(d, d, v);
-        }
-    const float rstd = 1.0f / sqrtf((v + __shfl_xor(v, 32)) * inv_n + 1e-5f);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x4 w[4], b[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            w[g] = wload(wb, wb.h16, (ln + ((t * 4 + g) * 2) * 4) * 4);
-            b[g] = wload(wb, wb.h16, (ln + NT * 32 + ((t * 4 + g) * 2) * 4) * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float y = fmaf((src[t][r] - mean) * rstd, w[r >> 2][r & 3], b[r >> 2][r & 3]);
-            dst[t][r] = fmaxf(y, 0.0f);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+// SAVE (training forward): the normalised values (x - mean) * rstd go to the T8 section `xhat_sec` of `tb` and the point's
+// rstd to float `rstd_off + point` -- the operands of the LayerNorm backward (ln_bwd, mlp_bwd.hip).
+struct TBuf;
+template <int NT, bool SAVE = false>
+__device__ __forceinline__ void ln_relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], const WBuf &wb, uint32_t ln,
+                                             const TBuf *tb = nullptr, uint32_t xhat_sec = 0, uint32_t rstd_off = 0);
 
 // relu_move with the NEXT layer's bias loads folded in: as soon as tile t has left the accumulator file its
 // registers are refilled with the next layer's bias, so those loads (an L2 round trip that the first MFMA of a layer
@@ -474,6 +444,56 @@ __device__ __forceinline__ TBuf make_tbuf(float *tile_base, int64_t tile_floats,
     t.m = (lane & 31) >> 3;
     t.q7 = lane & 7;
     return t;
+}
+
+template <int NT, bool SAVE>
+__device__ __forceinline__ void ln_relu_move(f32x16 (&dst)[NT], const f32x16 (&src)[NT], const WBuf &wb, uint32_t ln,
+                                             const TBuf *tb, uint32_t xhat_sec, uint32_t rstd_off) {
+    constexpr float inv_n = 1.0f / (32 * NT);
+    constexpr int C = 32 * NT;
+    asm volatile("" : "+s"(ln));
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += src[t][r];
+    const float mean = (s + __shfl_xor(s, 32)) * inv_n;
+    float v = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = src[t][r] - mean;
+            v = fmaf(d, d, v);
+        }
+    const float rstd = 1.0f / sqrtf((v + __shfl_xor(v, 32)) * inv_n + 1e-5f);
+    int voff = 0;
+    if constexpr (SAVE) {
+        voff = ((tb->m * C + 4 * tb->h) * 8 + tb->q7) * 4;
+        asm volatile("" : "+s"(xhat_sec), "+s"(rstd_off));
+        if (tb->h == 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), tb->rsrc, (tb->m * 8 + tb->q7) * 4, (int)(rstd_off * 4), 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 w[4], b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            w[g] = wload(wb, wb.h16, (ln + ((t * 4 + g) * 2) * 4) * 4);
+            b[g] = wload(wb, wb.h16, (ln + NT * 32 + ((t * 4 + g) * 2) * 4) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float xh = (src[t][r] - mean) * rstd;
+            if constexpr (SAVE)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xh), tb->rsrc, voff,
+                                                      (int)((xhat_sec + (32 * t + 8 * (r >> 2) + (r & 3)) * 8) * 4), 0);
+            const float y = fmaf(xh, w[r >> 2][r & 3], b[r >> 2][r & 3]);
+            dst[t][r] = fmaxf(y, 0.0f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // accumulator-layout registers (register r of tile t = channel 32t + (r&3) + 8(r>>2) + 4h) <-> T8 section

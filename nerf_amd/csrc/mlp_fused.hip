@@ -89,7 +89,12 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
         // out of the accumulators: ReLU (LN: LayerNorm first), and the next layer's bias goes in
         auto activate = [&](int l) {
             if constexpr (LN) {
-                ln_relu_move<NT>(hin, acc, wb, (uint32_t)(pl.ln_base + (int64_t)l * pl.ln_stride));
+                const uint32_t ln = (uint32_t)(pl.ln_base + (int64_t)l * pl.ln_stride);
+                if constexpr (TRAIN)     // the backward differentiates the normalisation from (x - mean) * rstd and rstd
+                    ln_relu_move<NT, true>(hin, acc, wb, ln, &tb, (uint32_t)a.tl.a_xhat + l * (32 * 32 * NT),
+                                           (uint32_t)a.tl.a_rstd + l * 32);
+                else
+                    ln_relu_move<NT>(hin, acc, wb, ln);
                 load_bias<NT>(acc, wb, bias_after(l));
             } else {
                 relu_move_bias<NT>(hin, acc, wb, bias_after(l));
@@ -159,7 +164,10 @@ __global__ void __launch_bounds__(256, 1) query_fwd_kernel(const QueryArgs a) {
                 }
                 if constexpr (TRAIN) store_in_t8<kKsD>(tb, (uint32_t)a.tl.a_din, din);
                 gemm_in<kKsD, NV>(acc2, din, wb, (uint32_t)pl.views_w_in);
-                if constexpr (LN) ln_relu_move<NV>(acc2, acc2, wb, (uint32_t)pl.views_ln);       // network.py:88-90
+                if constexpr (LN && TRAIN)                                                       // network.py:88-90
+                    ln_relu_move<NV, true>(acc2, acc2, wb, (uint32_t)pl.views_ln, &tb, (uint32_t)a.tl.a_xhat_v,
+                                           (uint32_t)a.tl.a_rstd + pl.n_trunk * 32);
+                else if constexpr (LN) ln_relu_move<NV>(acc2, acc2, wb, (uint32_t)pl.views_ln);
                 else relu_move<NV>(acc2, acc2, true);
                 if constexpr (TRAIN) {
                     store_acc_t8<NV>(tb, (uint32_t)a.tl.a_hv, acc2);
@@ -202,12 +210,16 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
         return check_launch("nrf_dnerf_straight_query_fwd");
     }
-    if (a.plan.layernorm) {   // inference kernels; the time net's goes through its training entry point (acts are written)
+    if (a.plan.layernorm) {   // the time net alone only has a training entry point (inference: one piece at a time through it)
         if constexpr (!EMB) {
             if (a.times) {
                 hipLaunchKernelGGL((query_fwd_kernel<NT, false, true, true, false, true>), dim3(blocks), dim3(256), 0, st, a);
                 return check_launch("nrf_dnerf_time_fwd_train (LayerNorm)");
             }
+        }
+        if (a.acts) {
+            hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, true, false, false, true>), dim3(blocks), dim3(256), 0, st, a);
+            return check_launch("nrf_query_fwd_train (LayerNorm)");
         }
         hipLaunchKernelGGL((query_fwd_kernel<NT, EMB, false, false, false, true>), dim3(blocks), dim3(256), 0, st, a);
         return check_launch("nrf_query_fwd (LayerNorm)");
@@ -274,8 +286,6 @@ static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const fl
     const char *e = straight ? plan_net(P, net, emb, net->reserved, true)
                              : plan_net(P, net, emb, times ? net->input_ch_views : 0);
     if (e) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: %s", e);
-    if (P.plan.layernorm && acts && !times)
-        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd_train: LayerNorm nets have no fused training kernels");
     if (n_points == 0) return NRF_OK;
     QueryArgs a{};
     a.times = times; a.t_div = t_div; a.t_stride = straight ? net->reserved : 1;
@@ -291,7 +301,7 @@ static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const fl
     }
     a.pts_per_ray = pts_per_ray > 0 ? pts_per_ray : 1;
     a.acts = acts;
-    a.tl = make_train_layout(P.plan.nt, P.plan.n_trunk, P.plan.use_viewdirs);
+    a.tl = make_train_layout(P.plan.nt, P.plan.n_trunk, P.plan.use_viewdirs, P.plan.layernorm);
     hipStream_t st = as_stream(stream);
     const bool emb1 = emb->mode != 0;
     switch (P.plan.nt) {
@@ -317,7 +327,7 @@ extern "C" int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const
 
 extern "C" int64_t nrf_train_acts_floats(const nrf_net_t *net, int64_t n_points) {
     if (!net || net->W % 32 || n_points < 0) return -1;
-    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, net->use_layernorm);
     return ((n_points + 31) / 32) * tl.a_tile;
 }
 

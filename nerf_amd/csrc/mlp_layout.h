@@ -114,6 +114,9 @@ struct TrainLayout {
     int64_t a_trunk;                 // D sections of W channels: post-ReLU outputs of trunk layer l
     int64_t a_feat, a_hv;            // feature_linear output (W), views layer output (W/2 padded to whole tiles, post-ReLU)
     int64_t a_mask;                  // ReLU gates as bits: D + 1 slots (trunk layers, view layer) of [64 lanes][4 dwords]
+    int64_t a_xhat, a_xhat_v;        // LayerNorm nets only: the normalised pre-activations (x - mean) * rstd of trunk layer l
+                                     // (D sections of W) and of the view layer: what the LayerNorm backward differentiates
+    int64_t a_rstd;                  // LayerNorm nets only: D + 1 slots of 32 floats: 1 / sqrt(var + eps) of each point
     int64_t a_tile;                  // floats per tile
     // gradients w.r.t. pre-activations
     int64_t g_trunk;                 // D sections of W
@@ -121,10 +124,12 @@ struct TrainLayout {
     int64_t g_hv;                    // W/2 padded to whole tiles
     int64_t g_head;                  // 32: rows 0..2 d/d(rgb)  (or d/d(output_linear out) rows 0..output_ch-1)
     int64_t g_xin;                   // 64: d/d(gamma(x)) in the reference's channel order (only written on request)
+    int64_t g_ln, g_ln_v;            // LayerNorm nets only: d/d(LayerNorm output) of trunk layer l (D sections of W) and of the
+                                     // view layer: with a_xhat, the operands of the affine parameters' gradients
     int64_t g_tile;
 };
 
-NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
+NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs, int layernorm = 0) {
     TrainLayout t{};
     t.nt = nt; t.n_trunk = D; t.use_viewdirs = use_viewdirs;
     const int W = 32 * nt;
@@ -137,6 +142,12 @@ NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
     t.a_feat = c; c += 32 * W;
     t.a_hv = c; c += 32 * Wv;
     t.a_mask = c; c += (int64_t)256 * (D + 1);
+    t.a_xhat = t.a_xhat_v = t.a_rstd = -1;
+    if (layernorm) {
+        t.a_xhat = c; c += (int64_t)32 * W * D;
+        t.a_xhat_v = c; c += 32 * Wv;
+        t.a_rstd = c; c += (int64_t)32 * (D + 1);
+    }
     t.a_tile = c;
     c = 0;
     t.g_trunk = c; c += (int64_t)32 * W * D;
@@ -144,6 +155,11 @@ NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs) {
     t.g_hv = c; c += 32 * Wv;
     t.g_head = c; c += 32 * 32;
     t.g_xin = c; c += 32 * 64;
+    t.g_ln = t.g_ln_v = -1;
+    if (layernorm) {
+        t.g_ln = c; c += (int64_t)32 * W * D;
+        t.g_ln_v = c; c += 32 * Wv;
+    }
     t.g_tile = c;
     return t;
 }

@@ -307,6 +307,13 @@ class PackedNet:
             gn.rgb_w, gn.rgb_b = g("rgb_linear.weight"), g("rgb_linear.bias")
         else:
             gn.out_w, gn.out_b = g("output_linear.weight"), g("output_linear.bias")
+        if n.use_layernorm:      # the affine parameters' gradients come out of the same pass (ln_param_grad_kernel)
+            if x3:
+                raise RuntimeError("nerf_amd: LayerNorm nets train on the f32 kernels (train_precision 'fp32')")
+            for i in range(n.D):
+                gn.ln_w[i], gn.ln_b[i] = g(f"pts_layernorms.{i}.weight"), g(f"pts_layernorms.{i}.bias")
+            if n.use_viewdirs:
+                gn.views_ln_w, gn.views_ln_b = g("views_layernorm.weight"), g("views_layernorm.bias")
         if x3 and self._bwd_fn() is not lib.nrf_query_bwd:      # deformation net: weight-gradient GEMMs on the bf16 pipe
             check(lib.nrf_dnerf_time_bwd_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
                                                 _ptr(self.bwd_x3_stream() if x3 != "wgrad" else None), _ptr(g_raw),

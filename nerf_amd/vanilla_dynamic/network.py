@@ -40,7 +40,8 @@ class _DeformFunction(torch.autograd.Function):
         # train_precision "bf16x3": the canonical net's forward and every weight-gradient GEMM as three bf16 MFMAs per
         # product, and the deformation net's activation-gradient chain; the deformation net's forward (dx feeds a frequency-512
         # encoding) and the canonical net's activation-gradient chain (which carries d/dx) stay exact f32
-        x3 = module.train_precision == "bf16x3" and module.W in (128, 256) and module.W_deform in (128, 256)
+        x3 = (module.train_precision == "bf16x3" and module.W in (128, 256) and module.W_deform in (128, 256)
+              and not module.use_layernorm)      # the LayerNorm backward is built in f32
         if module.train_precision not in ("fp32", "bf16x3"):
             raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', not {module.train_precision!r}")
         occ.refresh()
@@ -77,6 +78,8 @@ class _DeformFunction(torch.autograd.Function):
                 out.append(g_time.get("output_linear." + name[10:]))
             elif name.startswith("_time."):
                 out.append(g_time.get("pts_linears." + name[6:]))
+            elif name.startswith("_time_layernorms."):
+                out.append(g_time.get("pts_layernorms." + name[17:]))
             else:
                 out.append(None)
         return (None,) * 10 + tuple(out)
@@ -111,26 +114,32 @@ class NeRF(_StaticNeRF):
             params = {k: v for k, v in params.items() if not k.startswith("views_layernorm")}
         return params
 
+    def kernel_shape_reason(self, embedded_rows=False):
+        if self.use_layernorm and self.W not in (64, 128, 256):
+            return f"W = {self.W} with LayerNorm (the fused LayerNorm kernels are built for 64, 128, 256)"
+        return super().kernel_shape_reason(embedded_rows)
+
     def _ln_fused(self, x):
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return x.is_cuda and not need_grad and self.kernel_shape_reason(embedded_rows=True) is None
+        # the fused f32 kernels: the LayerNorm instantiation of the query kernel, and -- when parameters need gradients --
+        # its training twin with the LayerNorm backward inside the dgrad chain; d/d(embedded rows) is the composition's
+        return (x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad)
+                and self.kernel_shape_reason(embedded_rows=True) is None)
 
     def forward(self, x, ts=None):
         if self.use_layernorm and not self._ln_fused(x):
             out = self._forward_layernorm(x)
         else:
-            out = super().forward(x)      # the fused f32 kernel; use_layernorm: its LayerNorm instantiation (inference)
+            out = super().forward(x)
         return out, torch.zeros_like(x[:, :3])
 
     def query_points(self, pts, viewdirs, pts_per_ray, multires, multires_views):
-        if self.use_layernorm and self._need_grad(pts, input_grad_ok=True):
-            raise RuntimeError("nerf_amd: LayerNorm nets train through forward() (GPU torch composition); the fused "
-                               "query has no LayerNorm backward")
+        if self.use_layernorm and self.train_precision != "fp32" and self._need_grad(pts, input_grad_ok=True):
+            raise RuntimeError("nerf_amd: LayerNorm nets train on the f32 kernels only (train_precision = 'fp32')")
         return super().query_points(pts, viewdirs, pts_per_ray, multires, multires_views)
 
     def _forward_layernorm(self, x):
-        # LayerNorm variant (network.py:46-48, :75-76, :88-89) from GPU torch ops: what training differentiates (the fused
-        # kernels normalise in the forward only), and the fallback for widths without a fused kernel.
+        # LayerNorm variant (network.py:46-48, :75-76, :88-89) from GPU torch ops: taken when the caller differentiates
+        # w.r.t. the embedded rows, and for widths without a fused LayerNorm kernel.
         input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
         h = input_pts
         for i in range(self.D):
@@ -446,11 +455,13 @@ class DNeRF_Deformation(nn.Module):
         times = ops._f32(times, "times").reshape(-1)
         if self.use_layernorm:
             # network.py:276-300 + :46-48: both nets normalise between Linear and ReLU.  Inference runs the chain as its
-            # two halves on the LayerNorm instantiations of the f32 query kernel; training differentiates forward()'s
-            # GPU torch composition
+            # two halves on the LayerNorm instantiations of the f32 query kernel; training (below) on their training twins
             if self._training_call():
-                raise RuntimeError("nerf_amd: use_layernorm nets train through forward(); the fused kernels have no "
-                                   "LayerNorm backward")
+                if pts.requires_grad or times.requires_grad:
+                    raise NotImplementedError("nerf_amd: gradients w.r.t. points / times are not built (parameters only)")
+                return _DeformFunction.apply(self, pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
+                                             int(netchunk), multires, multires_views, multires_time,
+                                             *[p for _, p in self.named_parameters()])
             if self.precision != "fp32":
                 raise ValueError(f"nerf_amd: precision {self.precision!r} is not built for use_layernorm nets (fp32 only)")
             return self._query_points_two_launch(pts, viewdirs, times, int(pts_per_ray), bool(times_per_point),
@@ -496,8 +507,7 @@ class DNeRF_Deformation(nn.Module):
         ef = self.embed_fn
         return (pts_raw is not None and t_raw is not None and isinstance(ef, _EmbedFn) and ef.fusable
                 and ef.out_dim == self.input_ch and self.use_viewdirs and self.kernel_shape_reason() is None
-                and not (self.use_layernorm and (self._training_call() or self.W_deform not in (64, 128, 256)
-                                                 or self.W not in (64, 128, 256)))
+                and not (self.use_layernorm and (self.W_deform not in (64, 128, 256) or self.W not in (64, 128, 256)))
                 and (self.input_ch_views - 3) % 6 == 0 and (self.input_ch_time - 1) % 2 == 0
                 and (self.input_ch_views - 3) // 6 <= 4 and (self.input_ch_time - 1) // 2 <= 10
                 and x.is_cuda)

@@ -40,4 +40,28 @@ net = vd.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdir
 x = torch.randn(1 << 20, 90, device=dev)
 with torch.no_grad():
     out["layernorm_1M_rows_ms"] = {"fused": t(lambda: net(x)), "torch_composition": t(lambda: net._forward_layernorm(x))}
+
+
+# training pass (forward + backward of every parameter incl. the LayerNorm affine ones) on 256 K embedded rows: the fused
+# kernels (round 3: LayerNorm backward inside the dgrad chain) against the torch composition the module used before
+xt = torch.randn(1 << 18, 90, device=dev)
+gt = torch.randn(1 << 18, 4, device=dev)
+
+
+def train_pass(fwd):
+    net.zero_grad(set_to_none=True)
+    (fwd(xt) * gt).sum().backward()
+
+
+out["layernorm_256K_rows_train_ms"] = {"fused": t(lambda: train_pass(lambda v: net(v)[0])),
+                                        "torch_composition": t(lambda: train_pass(net._forward_layernorm))}
+plain = vd.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True).to(dev)
+
+
+def plain_pass():
+    plain.zero_grad(set_to_none=True)
+    (plain(xt)[0] * gt).sum().backward()
+
+
+out["layernorm_256K_rows_train_ms"]["plain_net_fused"] = t(plain_pass)
 print(json.dumps(out))

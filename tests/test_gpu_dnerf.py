@@ -188,8 +188,8 @@ def test_train_gradients_vs_reference(gold_dnerf, parts):
 
 
 def test_layernorm_variant_runs(parts):
-    """use_layernorm=True: reference-keyed parameters; training composes GPU torch ops, inference runs the LayerNorm
-    instantiations of the fused f32 kernel (tests/test_gpu_wellcond.py pins both to the reference)."""
+    """use_layernorm=True: reference-keyed parameters; inference and training both run the LayerNorm instantiations of the
+    fused f32 kernels (tests/test_gpu_wellcond.py pins both to the reference)."""
     vd, _, _, (embed_fn, embeddirs_fn, embed_time), _ = parts
     m = vd.DNeRF_Deformation(D=2, W=64, D_deform=2, W_deform=64, input_ch=63, input_ch_views=27, input_ch_time=21,
                              skips=[4], use_layernorm=True).cuda()
@@ -200,6 +200,19 @@ def test_layernorm_variant_runs(parts):
         raw, dx = vd.run_network_dnerf(pts, dev(fx.blender_rays(3, 1)[:, -3:]), torch.full((3, 1), 0.3, device="cuda"),
                                        m, embed_fn, embeddirs_fn, embed_time)
     assert raw.shape == (3, 8, 4) and dx.shape == (3, 8, 3) and torch.isfinite(raw).all()
+    # with gradients: the same call trains through the fused chain, every parameter of both nets gets a gradient
+    raw2, dx2 = vd.run_network_dnerf(pts, dev(fx.blender_rays(3, 1)[:, -3:]), torch.full((3, 1), 0.3, device="cuda"),
+                                     m, embed_fn, embeddirs_fn, embed_time)
+    fn, names = raw2.grad_fn, []
+    while fn is not None and len(names) < 4:           # run_network_dnerf reshapes the function's output
+        names.append(type(fn).__name__)
+        fn = fn.next_functions[0][0] if fn.next_functions else None
+    assert any("DeformFunction" in nm for nm in names), names
+    assert float((raw2.detach() - raw).abs().max()) <= 1e-5 * max(1.0, float(raw.abs().max()))
+    (raw2.sum() + dx2.sum()).backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert float(m._time_layernorms[0].weight.grad.abs().max()) > 0 and float(m._occ.views_layernorm.bias.grad.abs().max()) > 0
 
 
 def test_bf16_deformation_chain(gold_dnerf, parts):

@@ -50,7 +50,7 @@ def grad_summary(g):
     return np.concatenate([[g.sum(), np.sqrt((g * g).sum())], g[idx]])
 
 
-def check_grads(named_params, G, prefix, tol=2e-3):
+def check_grads(named_params, G, prefix, tol=2e-3, frac=0.95, dmax=10.0, stats=None):
     """Every parameter gradient against the reference autograd's summary (sum, norm, 256 strided samples)."""
     worst = 0.0
     for k, p in named_params:
@@ -70,7 +70,9 @@ def check_grads(named_params, G, prefix, tol=2e-3):
         if d.size < 20:      # 3-element biases: no fraction to speak of
             assert d.max() <= 2.0, (k, d)
         else:
-            assert (d <= 1.0).mean() >= 0.95 and d.max() <= 10.0, (k, float((d <= 1.0).mean()), float(d.max()))
+            assert (d <= 1.0).mean() >= frac and d.max() <= dmax, (k, float((d <= 1.0).mean()), float(d.max()))
+            if stats is not None:
+                stats["frac"], stats["dmax"] = min(stats.get("frac", 1.0), float((d <= 1.0).mean())), max(stats.get("dmax", 0.0), float(d.max()))
         worst = max(worst, abs(got[1] - ref[1]) / scale)
     return worst
 
@@ -413,18 +415,102 @@ def test_layernorm_networks_vs_reference(d2, dparts, tag, D, W, skips, seed):
     print(f"LayerNorm {tag}: fused vs golden dx {np.abs(host(fdx) - d2[f'ln_{tag}_dx']).max():.2e}, out "
           f"{np.abs(host(fo) - ref).max():.2e}; composed vs golden out {np.abs(host(co) - ref).max():.2e}")
     m.zero_grad()
+    m._time_net = None       # with gradients: the fused training chain (_DeformFunction on the LayerNorm kernels, round 3)
     out, dx = m(xin, [te, te], pts_raw=pts, t_raw=tt)
+    assert m._time_net is not None and out.grad_fn is not None and "DeformFunction" in type(out.grad_fn).__name__, \
+        "the fused LayerNorm training chain did not run"
     np.testing.assert_allclose(host(dx), d2[f"ln_{tag}_dx"], atol=2e-5, rtol=0)
     ref = d2[f"ln_{tag}_out"]
     np.testing.assert_allclose(host(out), ref, atol=1e-3 * max(1.0, np.abs(ref).max()), rtol=0)
     ((out * dev(d2[f"ln_{tag}_gw"])).sum() + (dx * dev(d2[f"ln_{tag}_gd"])).sum()).backward()
+    # The fused chain's x + dx is 3.7e-7 from the reference's (as the composition's is, in another direction) and goes through a
+    # frequency-512 encoding: on the small model ONE of the 320 points then has a ReLU gate of the canonical trunk on the
+    # other side (its input gradient is 2.8 % off, every other point within 8e-5), which moves the strided samples of the
+    # trunk gradients it feeds (norms up to 2.5e-3 off) and, through d/d(x + dx), every gradient of the deformation net (8e-3:
+    # that point's input gradient is among the largest).  Hence the wider bars here; on identical points the same kernels
+    # agree with float64 autograd to 4e-7 (test_layernorm_fused_chain_on_identical_points), and the composition below --
+    # whose roundings follow the reference's op for op -- keeps the standard bars.
+    st = {}
+    worst = check_grads(m.named_parameters(), d2, f"ln_{tag}_grad_", tol=2e-2, stats=st)
+    print(f"LayerNorm {tag}: fused training chain, worst gradient-norm error {worst:.2e}; strided samples within the bar: "
+          f">= {st['frac']:.3f} of a tensor's, worst {st['dmax']:.1f} x the bar")
+    m.zero_grad()
+    co, cdx = m._forward_torch(xin, [te, te], pts, tt)           # what a caller that differentiates w.r.t. x gets
+    ((co * dev(d2[f"ln_{tag}_gw"])).sum() + (cdx * dev(d2[f"ln_{tag}_gd"])).sum()).backward()
     worst = check_grads(m.named_parameters(), d2, f"ln_{tag}_grad_")
-    print(f"LayerNorm {tag}: worst gradient-norm error {worst:.2e}")
+    print(f"LayerNorm {tag}: composition, worst gradient-norm error {worst:.2e}")
+
+
+@pytest.mark.parametrize("tag,D,W,skips,seed", [("small", 3, 64, (1,), 51), ("full", 8, 256, (4,), 52)])
+def test_layernorm_fused_chain_on_identical_points(d2, dparts, tag, D, W, skips, seed):
+    """The two halves of the fused LayerNorm training chain against float64 autograd with the conditioning taken out: the
+    deformation net alone (dx and every gradient for a given d/d(dx)), and the canonical net at the float64 chain's x + dx
+    rounded once (parameter gradients and d/d(x + dx), the quantity that links the halves)."""
+    import torch.nn.functional as F
+    from nerf_amd.vanilla_dynamic.network import _layer_norm
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time) = dparts
+    sd = fx.make_dnerf_layernorm_state(seed, D=D, W=W, D_deform=D, W_deform=W, skips=skips)
+
+    def mk():
+        m = vd.DNeRF_Deformation(D=D, W=W, D_deform=D, W_deform=W, input_ch=63, input_ch_views=27, input_ch_time=21,
+                                 output_ch=4, skips=list(skips), use_viewdirs=True, zero_canonical=True, use_layernorm=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        return m.cuda()
+
+    def emb64(x, L):
+        return torch.cat([x] + [f(x * 2.0 ** k) for k in range(L) for f in (torch.sin, torch.cos)], -1)
+
+    m, m64 = mk(), mk().double()
+    m.embed_fn = embed_fn
+    pts, dirs, tt = dev(d2["ln_pts"]), dev(d2["ln_dirs"]), dev(d2["ln_times"])
+    gw, gd = dev(d2[f"ln_{tag}_gw"]), dev(d2[f"ln_{tag}_gd"])
+    n = pts.shape[0]
+    tnet = m._time_packed(10, 10)
+    dx, acts_t = tnet.query_train(pts, tt.reshape(-1), 1, True)
+    g_time = tnet.query_bwd(gd.contiguous(), n, acts_t)
+    p64 = pts.double()
+    ip = emb64(p64, 10)
+    h = torch.cat([ip, emb64(tt.double(), 10)], -1)
+    for i in range(D):
+        h = F.relu(_layer_norm(m64._time[i](h), m64._time_layernorms[i]))
+        if i in skips:
+            h = torch.cat([ip, h], -1)
+    dx64 = m64._time_out(h)
+    (dx64 * gd.double()).sum().backward()
+    assert float((dx.double() - dx64.detach()).abs().max()) <= 2e-6
+    p64s = dict(m64.named_parameters())
+    worst = 0.0
+    for k, v in g_time.items():
+        name = k.replace("pts_linears.", "_time.").replace("output_linear.", "_time_out.").replace("pts_layernorms.", "_time_layernorms.")
+        e = float((v.double() - p64s[name].grad).norm() / p64s[name].grad.norm())
+        worst = max(worst, e)
+        assert e <= 2e-5, (name, e)
+    occ = m._occ._packed((0, 10, 4))
+    x2 = (p64 + dx64.detach()).float().contiguous()         # rounded once; the float64 reference starts from the rounded points
+    x2_64 = x2.double().requires_grad_(True)
+    o64 = m64._occ._forward_layernorm(torch.cat([emb64(x2_64, 10), emb64(dirs.double(), 4)], -1))
+    (o64 * gw.double()).sum().backward()
+    raw, acts_c = occ.query_train(x2, dirs, 1)
+    g_occ, g_x2 = occ.query_bwd(gw.contiguous(), n, acts_c, pts=x2)
+    assert float((raw.double() - o64.detach()).abs().max()) <= 1e-4 * max(1.0, float(o64.detach().abs().max()))
+    # f32 against f64 on ~10^5..10^6 ReLU gates: a pre-activation within rounding of zero gates differently in the two
+    # arithmetics (the full model has one such point: its input gradient is 1.6 % off, all others within 1e-4), so
+    # parameter gradients and d/d(x + dx) are held to 5e-3 of their norms, and d/d(x + dx) to 1e-4 on all but two points
+    # (the small model, with no such point: 4e-7)
+    per_pt = (g_x2.double() - x2_64.grad).abs().max(-1).values / x2_64.grad.abs().max()
+    e_x = float((g_x2.double() - x2_64.grad).norm() / x2_64.grad.norm())
+    assert e_x <= 5e-3 and int((per_pt > 1e-4).sum()) <= 2, (e_x, int((per_pt > 1e-4).sum()))
+    for k, v in g_occ.items():
+        q = p64s["_occ." + k].grad
+        e = float((v.double() - q).norm() / q.norm())
+        worst = max(worst, e)
+        assert e <= 5e-3, (k, e)
+    print(f"LayerNorm {tag}: fused halves on identical points: worst parameter-gradient error {worst:.2e}, d/d(x+dx) {e_x:.2e}")
 
 
 def test_layernorm_fused_other_shapes_and_refusals(dparts):
     """W = 128 / no view directions / ragged point counts: the fused LayerNorm kernels against the GPU torch composition of
-    the same module; what the fused path does not build (bf16 arithmetic, the backward) fails loudly."""
+    the same module; what the fused path does not build (16-bit arithmetic, inference or training) fails loudly."""
     vd, _, _, (embed_fn, embeddirs_fn, embed_time) = dparts
     rs = np.random.RandomState(5)
     for W, D, skips, views, n in ((128, 4, [2], True, 77), (64, 2, [], False, 33), (256, 3, [0], True, 1)):
@@ -442,11 +528,76 @@ def test_layernorm_fused_other_shapes_and_refusals(dparts):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (W, D, float((a - b).abs().max()))
     net = vd.NeRF(D=3, W=128, input_ch=63, input_ch_views=27, skips=[1], use_viewdirs=True, use_layernorm=True).cuda()
     pts = dev(rs.uniform(-1, 1, (64, 3)))
+    net.train_precision = "bf16x3"
     with pytest.raises(RuntimeError, match="LayerNorm"):
-        net.query_points(pts, dev(rs.normal(size=(64, 3))), 1, 10, 4)              # training query: no fused backward
+        net.query_points(pts, dev(rs.normal(size=(64, 3))), 1, 10, 4)              # training query: f32 kernels only
     net.precision = "bf16"
     with torch.no_grad(), pytest.raises(RuntimeError, match="LayerNorm"):
         net.query_points(pts, dev(rs.normal(size=(64, 3))), 1, 10, 4)
+
+
+def _randomise_layernorms(net, rs):
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "layernorm" in n:
+                p.copy_(dev(rs.uniform(0.5, 1.5, p.shape) if n.endswith("weight") else rs.uniform(-0.3, 0.3, p.shape)))
+
+
+@pytest.mark.parametrize("W,D,skips,views,n", [(64, 2, [], False, 33), (128, 4, [2], True, 77), (256, 3, [0], True, 1),
+                                               (256, 8, [4], True, 300), (64, 1, [], True, 40)])
+def test_layernorm_fused_training_vs_float64_autograd(dparts, W, D, skips, views, n):
+    """The fused LayerNorm TRAINING path (round 3: nrf_query_fwd_train saves (x - mean) * rstd and rstd; the dgrad chain runs
+    the LayerNorm backward in registers, ln_param_grad_kernel the affine parameters' gradients): forward(x) on embedded rows
+    and query_points on raw points (incl. d/d(points), the D-NeRF chain's input gradient) against float64 autograd of the
+    module's own torch composition (vanilla_dynamic/network.py:46-48, :75-76, :88-89)."""
+    import copy
+    vd, _, _, (embed_fn, embeddirs_fn, embed_time) = dparts
+    rs = np.random.RandomState(W + D)
+    net = vd.NeRF(D=D, W=W, input_ch=63, input_ch_views=27, output_ch=5, skips=skips, use_viewdirs=views,
+                  use_layernorm=True).cuda()
+    _randomise_layernorms(net, rs)
+    net64 = copy.deepcopy(net).double()
+    pts, dirs = dev(rs.uniform(-1, 1, (n, 3))), dev(rs.normal(size=(n, 3)))
+    oc = 4 if views else 5
+    gw = dev(rs.normal(size=(n, oc)))
+
+    def emb64(x, L):
+        return torch.cat([x] + [f(x * 2.0 ** k) for k in range(L) for f in (torch.sin, torch.cos)], -1)
+
+    # (a) forward(x) on embedded rows: parameter gradients
+    x = torch.cat([embed_fn(pts), embeddirs_fn(dirs)], -1)
+    net._packed_cache = {}
+    out, _ = net(x)
+    assert net._packed_cache, "the fused LayerNorm training kernel did not run"
+    (out * gw).sum().backward()
+    ref = net64._forward_layernorm(x.double())
+    assert float((out.detach().double() - ref.detach()).abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    (ref * gw.double()).sum().backward()
+    worst = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), net64.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        e = float((p.grad.double() - q.grad).norm()) / max(float(q.grad.norm()), 1e-30)
+        worst = max(worst, e)
+        assert e <= 2e-4, (k, e)
+    # (b) query_points on raw points with d/d(points)
+    net.zero_grad(); net64.zero_grad()
+    p32 = pts.clone().requires_grad_(True)
+    raw = net.query_points(p32, dirs, 1, 10, 4)
+    (raw * gw).sum().backward()
+    p64 = pts.double().requires_grad_(True)
+    ref = net64._forward_layernorm(torch.cat([emb64(p64, 10), emb64(dirs.double(), 4)], -1))
+    (ref * gw.double()).sum().backward()
+    assert float((raw.detach().double() - ref.detach()).abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    e_pts = float((p32.grad.double() - p64.grad).abs().max()) / float(p64.grad.abs().max())
+    assert e_pts <= 2e-4, e_pts
+    for (k, p), (_, q) in zip(net.named_parameters(), net64.named_parameters()):
+        if q.grad is not None:
+            e = float((p.grad.double() - q.grad).norm()) / max(float(q.grad.norm()), 1e-30)
+            worst = max(worst, e)
+            assert e <= 2e-4, (k, e)
+    print(f"LayerNorm fused training W={W} D={D}: worst parameter-gradient error {worst:.2e}, d/d(points) {e_pts:.2e}")
 
 
 def test_straightforward_vs_reference(d2, dparts):
