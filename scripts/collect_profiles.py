@@ -55,7 +55,7 @@ def main(tag, rnd):
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for w in ("render", "train", "train_bf16x3", "dnerf", "dnerf_bf16", "dnerf_bf16x3", "render_bf16", "render_bf16x3",
-              "dnerf_straight"):
+              "dnerf_straight", "fern"):
         p = os.path.join(src, f"stats_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{rnd}_{w}_kernel_stats.csv"))

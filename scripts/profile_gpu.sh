@@ -56,6 +56,8 @@ for what in "$@"; do
       done ;;
     stats_straight)   # network_type='straightforward' (render fp32 / bf16x3, training step) and the LayerNorm kernel
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dnerf_straight" -o dnerf_straight -- python3 $ROOT/scripts/bench_straight.py > "$OUT/dnerf_straight_stats.log" 2>&1 ;;
+    stats_fern)    # BASELINE configs[3]: the 1008x756 NDC view (configs/fern.txt), 64+128 samples, f32
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_fern" -o fern -- python3 $ROOT/bench.py --workload fern --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/fern_stats.log" 2>&1 ;;
     stats_dnerf)   # the deformation chain at the three precisions, one kernel-trace run each
       for P in fp32 bf16 bf16x3; do
         W=dnerf_$P; [ $P = fp32 ] && W=dnerf
