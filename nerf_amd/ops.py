@@ -349,6 +349,12 @@ class PackedNet:
         bf16x3 kernel (the library then runs that chain in f32)."""
         if self.emb.mode != 0 or self.net.W not in (128, 256) or self.net.D < 2:
             return None
+        # the pack reads the LIVE parameters, the f32 copy and the saved activations belong to the last refresh(): a
+        # parameter changed in between must not be packed under the old label
+        live = tuple((v.data_ptr(), v._version) for v in self.params.values())
+        if live != self._versions:
+            raise RuntimeError("nerf_amd: a parameter of this network was modified after its weights were packed for the "
+                               "forward; the backward's W^T stream would not match the saved activations")
         if getattr(self, "_bwd_x3_versions", None) != self._versions or getattr(self, "_bwd_x3", None) is None:
             lib = _lib.lib()
             nb = lib.nrf_mlp_bf16x3_bwd_packed_bytes(C.byref(self.net), C.byref(self.emb))
