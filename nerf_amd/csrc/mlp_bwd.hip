@@ -853,8 +853,8 @@ static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles, int max_chunks = 25
 }
 
 extern "C" int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points) {
-    if (!net || net->W % 32 || n_points < 0) return -1;
-    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, net->use_layernorm);
+    if (!net || net->W < 2 || net->W > 256 || n_points < 0) return -1;
+    TrainLayout tl = make_train_layout((net->W + 31) / 32, net->D, net->use_viewdirs, net->use_layernorm);
     return ((n_points + 31) / 32) * tl.g_tile;
 }
 
@@ -864,12 +864,13 @@ static int64_t ln_partial_floats(const nrf_net_t *net) {
 }
 
 static int64_t slab_floats(const nrf_net_t *net, int64_t n_points, int max_chunks) {
-    if (!net || net->W % 32 || n_points < 0) return -1;
+    if (!net || net->W < 2 || net->W > 256 || n_points < 0) return -1;
     int ct;
     int64_t nchunks = pick_chunks((n_points + 31) / 32, &ct, max_chunks);
     // every GEMM of the pass (<= D trunk layers + 3 heads) keeps its own slab region; bound on each:
     // (feature + alpha row) x cat[hidden, gamma(x), gamma(t)]
-    int64_t np = net->W + 32, kp = net->W + 2 * kKsX + 32;
+    const int64_t wp = (net->W + 31) / 32 * 32;      // the kernels' width: whole 32-channel tiles
+    int64_t np = wp + 32, kp = wp + 2 * kKsX + 32;
     return nchunks * (net->D + 3) * (np * kp + np) + ln_partial_floats(net);
 }
 
@@ -897,7 +898,9 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
             return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_input: input gradients need the fused encoding (embed mode 0)");
     }
     const NetPlan &pl = P.plan;
-    const int nt = pl.nt, W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
+    // W: the net's width (valid rows / columns of the gradients); Wp: the kernels' width in whole 32-channel tiles (the
+    // T8 sections' channel count; equal unless W is zero-padded)
+    const int nt = pl.nt, W = net->W, Wp = 32 * nt, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
     hipStream_t st = as_stream(stream);
     DgradArgs d{};
     d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs, pl.layernorm);
@@ -967,7 +970,7 @@ dgrad_done:
         int ne = 0;
         for (int l = 0; l < D; ++l) {
             NRF_REQUIRE(grads->ln_w[l] && grads->ln_b[l], "nrf_query_bwd: grads->ln_w/ln_b[%d] is null", l);
-            la.e[ne++] = LnGradEntry{d.tl.g_ln + (int64_t)l * 32 * W, d.tl.a_xhat + (int64_t)l * 32 * W, W, W,
+            la.e[ne++] = LnGradEntry{d.tl.g_ln + (int64_t)l * 32 * Wp, d.tl.a_xhat + (int64_t)l * 32 * Wp, Wp, W,
                                      const_cast<float *>(grads->ln_w[l]), const_cast<float *>(grads->ln_b[l])};
         }
         if (pl.use_viewdirs) {
@@ -985,7 +988,7 @@ dgrad_done:
     const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};
     for (int l = 0; l < D; ++l) {
         NRF_REQUIRE(grads->pts_w[l] && grads->pts_b[l], "nrf_query_bwd: grads->pts_w/pts_b[%d] is null", l);
-        const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * W;
+        const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * Wp;
         bool skip = l > 0 && ((net->skips_mask >> (l - 1)) & 1);
         const int skip_ch = ic + (straight ? time_ch : 0);     // a straightforward net's skip reads cat[gamma(x), gamma(t), h]
         int ld = l == 0 ? ic + time_ch : (W + (skip ? skip_ch : 0));
@@ -997,28 +1000,28 @@ dgrad_done:
             parts[np++] = Xin;
             if (time_ch) parts[np++] = Tin;   // columns fed by gamma(t) (vanilla_dynamic/network.py:296, :176)
         } else {
-            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * 32 * W, W, nt, BLK_HIDDEN, 0, 0, W, skip ? skip_ch : 0};
+            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * 32 * Wp, Wp, nt, BLK_HIDDEN, 0, 0, W, skip ? skip_ch : 0};
             if (skip) parts[np++] = Xin;   // network.py:52-53: cat[input_pts, h]
         }
-        rc = B.run(gsec, W, nt, parts, np, ld, &dst, 1);
+        rc = B.run(gsec, Wp, nt, parts, np, ld, &dst, 1);
         if (rc) return rc;
         if (l > 0 && skip && straight) {   // the gamma(t) columns of the skip layer: a GEMM of their own (no bias)
             Bwd::Dst dt{0, W, grads->pts_w[l], nullptr};
-            rc = B.run(gsec, W, nt, &Tin, 1, ld, &dt, 1);
+            rc = B.run(gsec, Wp, nt, &Tin, 1, ld, &dt, 1);
             if (rc) return rc;
         }
     }
-    const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * 32 * W;
-    const Bwd::XPart Hlast{a_last, W, nt, BLK_HIDDEN, 0, 0, W, 0};
+    const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * 32 * Wp;
+    const Bwd::XPart Hlast{a_last, Wp, nt, BLK_HIDDEN, 0, 0, W, 0};
     if (pl.use_viewdirs) {
         NRF_REQUIRE(grads->feature_w && grads->feature_b && grads->alpha_w && grads->alpha_b && grads->views_w &&
                     grads->views_b && grads->rgb_w && grads->rgb_b, "nrf_query_bwd: a head gradient pointer is null");
-        Bwd::Dst fd[2] = {{0, W, grads->feature_w, grads->feature_b}, {W, 1, grads->alpha_w, grads->alpha_b}};
-        rc = B.run(tl.g_feat, W + 32, nt + 1, &Hlast, 1, W, fd, 2);
+        Bwd::Dst fd[2] = {{0, W, grads->feature_w, grads->feature_b}, {Wp, 1, grads->alpha_w, grads->alpha_b}};   // d/d(alpha): row Wp
+        rc = B.run(tl.g_feat, Wp + 32, nt + 1, &Hlast, 1, W, fd, 2);
         if (rc) return rc;
         const int nv = (nt + 1) / 2;          // tiles of the view layer: W/2 live channels, zero-padded to 32 * nv
         Bwd::Dst vd{0, W / 2, grads->views_w, grads->views_b};
-        Bwd::XPart vparts[2] = {{tl.a_feat, W, nt, BLK_HIDDEN, 0, 0, W, 0},
+        Bwd::XPart vparts[2] = {{tl.a_feat, Wp, nt, BLK_HIDDEN, 0, 0, W, 0},
                                 {tl.a_din, 2 * kKsD, dk, pl.d_type, pl.d_param, kKsD, 0, W}};   // network.py:58: cat[feature, views]
         rc = B.run(tl.g_hv, 32 * nv, nv, vparts, 2, W + icv, &vd, 1);
         if (rc) return rc;
@@ -1126,7 +1129,7 @@ extern "C" int nrf_query_bwd_static(const nrf_net_t *net, const nrf_embed_t *emb
     const int64_t need_s = slab_floats(net, n_points, kStaticMaxChunks);
     if (raw_g < 0 || need_s < 0)      // tested BEFORE the rounding below, which would turn the -1 of an unsupported shape into 0
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_static: unsupported network shape (D %d, W %d: the backward "
-                         "kernels take W a multiple of 32 up to 256 and D <= 16)", net->D, net->W);
+                         "kernels take W up to 256 and D <= 16)", net->D, net->W);
     const int64_t need_g = (raw_g + 63) & ~(int64_t)63;     // keep `slab` 256-byte aligned
     if (need_g + need_s > kStaticScratchFloats) {
         // the slab part is constant beyond kStaticMaxChunks tiles; gbuf grows by g_tile floats per 32 points

@@ -41,8 +41,8 @@ static __global__ void __launch_bounds__(256) pack_kernel(PackArgs a, float *__r
             int t = rest % s.nt_out, G = rest / s.nt_out;
             int h = lane >> 5, n = 32 * t + (lane & 31);
             int c = blk_chan(s.blk_type, s.blk_param, s.blk_ks, h, 4 * G + i);
-            if (!s.transposed) {
-                if (c >= 0 && n < s.n_out) v = s.src[(int64_t)n * s.ld + s.ch_off + c];
+            if (!s.transposed) {   // n_src > 0: live input channels of a hidden block whose last tile is zero padding
+                if (c >= 0 && n < s.n_out && (s.n_src <= 0 || c < s.n_src)) v = s.src[(int64_t)n * s.ld + s.ch_off + c];
             } else {
                 if (c >= 0 && c < s.n_src && n < s.n_out) v = s.src[(int64_t)c * s.ld + s.ch_off + n];
             }
@@ -81,10 +81,11 @@ struct Planner {
         if (pack.nsec >= kPlanSecs) { err = "too many weight sections"; return; }
         pack.sec[pack.nsec++] = s;
     }
-    int64_t gemm_block(const float *w, int ld, int n_out, int nt_out, int type, int param, int ks, int ch_off) {
+    // k_valid > 0: a hidden input block of which only the first k_valid channels exist (W not a multiple of 32)
+    int64_t gemm_block(const float *w, int ld, int n_out, int nt_out, int type, int param, int ks, int ch_off, int k_valid = 0) {
         int count = (ks / 4) * nt_out * 256;
         int64_t o = alloc(count);
-        add(PackSec{w, o, 0, ld, n_out, nt_out, type, param, ks, ch_off, count, 0, 0, 0});
+        add(PackSec{w, o, 0, ld, n_out, nt_out, type, param, ks, ch_off, count, 0, k_valid, 0});
         return o;
     }
     // W^T block for dgrad: [4*nt_src groups][nt_out tiles]: out rows = W's input channels k_off.. (k_valid of
@@ -136,7 +137,11 @@ static inline int launch_pack(const Planner &P, float *packed, hipStream_t st, c
 static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, bool straight = false) {
     NetPlan &pl = P.plan;
     const int W = net->W, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
-    if (W < 32 || W > 256 || W % 32) return "W must be a multiple of 32 in [32, 256]";
+    // any --netwidth up to 256 (config.py:20-27 takes anything): the kernels run whole 32-channel tiles, a width that is
+    // not a multiple of 32 is zero-padded in the packed weights (zero rows and bias -> the extra channels stay 0 through
+    // every ReLU; zero columns in the consumers) -- same sums, same results
+    if (W < 2 || W > 256) return "W must be in [2, 256]";
+    if (net->use_layernorm && W % 32) return "LayerNorm nets need W to be a multiple of 32 (the statistics run over whole tiles)";
     if (D < 1 || D > NRF_MAX_D) return "D must be in [1, 16]";
     // a skip index >= D never fires in the reference's loop (network.py:49-53) and is ignored here too; index D - 1
     // would widen the trunk's output, which the reference's heads cannot take either
@@ -148,10 +153,10 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
     pl.straight = straight;
     // the view layer has W/2 outputs (network.py:40): nv whole tiles, the last one zero-padded when W/2 is not a multiple
     // of 32 (W = 96, 160, 224; --netwidth accepts anything, config.py:20-27)
-    const int nv = (W / 2 + 31) / 32;
+    const int nv = ((W + 31) / 32 + 1) / 2;   // = the kernels' NV = (NT + 1) / 2 (>= the tiles W/2 needs)
     if (views && net->use_layernorm && (W / 2) % 32)
         return "LayerNorm nets with view directions need W/2 to be a multiple of 32 (the statistics run over whole tiles)";
-    pl.nt = W / 32;
+    pl.nt = (W + 31) / 32;
     pl.n_trunk = D;
     pl.use_viewdirs = views;
     pl.output_ch = (time_ch && !straight) ? 3 : (views ? 4 : net->output_ch);
@@ -198,7 +203,7 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
         int ld = W + (skip ? skip_ch : 0);
         int64_t slot = P.cur;
         P.bias(net->pts_b[i], W, nt);
-        P.gemm_block(net->pts_w[i], ld, W, nt, BLK_HIDDEN, 0, 16 * nt, skip ? skip_ch : 0);
+        P.gemm_block(net->pts_w[i], ld, W, nt, BLK_HIDDEN, 0, 16 * nt, skip ? skip_ch : 0, W);
         if (skip) {
             pl.skip_in_mask |= 1 << i;
             P.gemm_block(net->pts_w[i], ld, W, nt, pl.x_type, pl.x_param, kKsX, 0);
@@ -210,15 +215,15 @@ static const char *plan_net(Planner &P, const nrf_net_t *net, const nrf_embed_t 
         if (P.cur - slot != pl.trunk_stride) return "internal: trunk slot size mismatch";
     }
     if (views) {
-        P.head(net->alpha_w, net->alpha_b, W, 1, nt, 0, pl.alpha_vec, pl.alpha_b);                  // network.py:56
-        pl.feat_w = P.gemm_block(net->feature_w, W, W, nt, BLK_HIDDEN, 0, 16 * nt, 0);               // network.py:57
+        P.head(net->alpha_w, net->alpha_b, W, 1, nt, 0, pl.alpha_vec, pl.alpha_b, W);                  // network.py:56
+        pl.feat_w = P.gemm_block(net->feature_w, W, W, nt, BLK_HIDDEN, 0, 16 * nt, 0, W);               // network.py:57
         pl.feat_b = P.bias(net->feature_b, W, nt);
-        pl.views_w_hid = P.gemm_block(net->views_w, W + icv, W / 2, nv, BLK_HIDDEN, 0, 16 * nt, 0);  // :58-62
+        pl.views_w_hid = P.gemm_block(net->views_w, W + icv, W / 2, nv, BLK_HIDDEN, 0, 16 * nt, 0, W);  // :58-62
         pl.views_w_in = P.gemm_block(net->views_w, W + icv, W / 2, nv, pl.d_type, pl.d_param, kKsD, W);
         pl.views_b = P.bias(net->views_b, W / 2, nv);
         P.head(net->rgb_w, net->rgb_b, W / 2, 3, nv, 0, pl.rgb_vec, pl.rgb_b, W / 2);                // network.py:64
     } else {
-        P.head(net->out_w, net->out_b, W, pl.output_ch, nt, 0, pl.out_vec, pl.out_b);               // network.py:67
+        P.head(net->out_w, net->out_b, W, pl.output_ch, nt, 0, pl.out_vec, pl.out_b, W);               // network.py:67
     }
     pl.layernorm = net->use_layernorm != 0;
     if (pl.layernorm) {   // vanilla_dynamic/network.py:46-48 (or :275-277 for the time net): affine parameters in bias order

@@ -242,8 +242,8 @@ static int launch_query(const QueryArgs &a, hipStream_t st) {
 template <int NT, bool EMB>
 static int launch_query_plain(const QueryArgs &a, hipStream_t st) {
     if (a.plan.straight || a.plan.layernorm || a.times)
-        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d: the D-NeRF time / straightforward and LayerNorm kernels are "
-                         "built for W = 64, 128, 256", NT * 32);
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: %d channel tiles: the D-NeRF time / straightforward and LayerNorm "
+                         "kernels are built for 2, 4 and 8 tiles (W = 64, 128, 256 and the widths padded to them)", NT);
     int64_t ntiles = (a.n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > 256) blocks = 256;
@@ -315,7 +315,7 @@ static int query_fwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, const fl
         case 6: return emb1 ? launch_query_plain<6, true>(a, st) : launch_query_plain<6, false>(a, st);
         case 7: return emb1 ? launch_query_plain<7, true>(a, st) : launch_query_plain<7, false>(a, st);
         default:
-            return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d has no fused kernel (multiples of 32 up to 256 do)", net->W);
+            return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_fwd: W = %d has no fused kernel (widths up to 256 do)", net->W);
     }
 }
 
@@ -326,8 +326,8 @@ extern "C" int nrf_query_fwd(const nrf_net_t *net, const nrf_embed_t *emb, const
 }
 
 extern "C" int64_t nrf_train_acts_floats(const nrf_net_t *net, int64_t n_points) {
-    if (!net || net->W % 32 || n_points < 0) return -1;
-    TrainLayout tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, net->use_layernorm);
+    if (!net || net->W < 2 || net->W > 256 || n_points < 0) return -1;
+    TrainLayout tl = make_train_layout((net->W + 31) / 32, net->D, net->use_viewdirs, net->use_layernorm);
     return ((n_points + 31) / 32) * tl.a_tile;
 }
 

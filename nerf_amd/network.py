@@ -158,8 +158,8 @@ class NeRF(nn.Module):
         """None when the fused kernels are built for this architecture, else the reason (supported ranges).
         The reference has no such limits: architectures outside them run the same arithmetic as a GPU torch composition
         (forward() on embedded rows, which is also what render.run_network's generic route calls), announced once."""
-        if self.W % 32 or not 32 <= self.W <= 256:
-            return f"W = {self.W} (the fused kernels take widths that are multiples of 32, up to 256)"
+        if not 2 <= self.W <= 256:
+            return f"W = {self.W} (the fused kernels take widths up to 256)"
         if self.D > 16:
             return f"D = {self.D} (the fused kernels take D <= 16)"
         if not self.use_viewdirs and self.output_ch > 8:

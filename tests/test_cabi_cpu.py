@@ -57,8 +57,8 @@ def test_version_and_size_queries():
 
 
 @pytest.mark.parametrize("kw,msg", [
-    (dict(W=100), "multiple of 32"),
-    (dict(W=512), "multiple of 32"),
+    (dict(W=1), "W must be"),
+    (dict(W=512), "W must be"),
     (dict(D=17), "D must be"),
     (dict(ic=60), "input_ch == 3"),
     (dict(icv=30), "input_ch_views == 3"),
@@ -70,6 +70,18 @@ def test_unsupported_shapes_are_reported(kw, msg):
     n, e = net(**kw), NrfEmbed(0, 10, 4, 0)
     assert l.nrf_mlp_packed_floats(C.byref(n), C.byref(e)) <= 0
     assert msg in l.nrf_last_error_string().decode()
+
+
+def test_any_width_up_to_256_packs_in_whole_tiles():
+    """--netwidth takes any value (config.py:20-27): a width that is not a multiple of 32 is zero-padded to whole 32-channel
+    tiles, so its packed weights and workspaces have the next multiple's sizes."""
+    l = _lib.lib()
+    e = NrfEmbed(0, 10, 4, 0)
+    for W, Wp in ((100, 128), (33, 64), (250, 256), (2, 32)):
+        a, b = net(W=W), net(W=Wp)
+        assert l.nrf_mlp_packed_floats(C.byref(a), C.byref(e)) == l.nrf_mlp_packed_floats(C.byref(b), C.byref(e)) > 0
+        for f in (l.nrf_train_acts_floats, l.nrf_train_grads_floats, l.nrf_train_slab_floats):
+            assert f(C.byref(a), 1000) == f(C.byref(b), 1000) > 0
 
 
 def test_null_and_bad_arguments_fail_before_launch():

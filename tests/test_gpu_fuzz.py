@@ -64,10 +64,11 @@ def test_random_net_query_all_precisions(seed):
 
 
 @pytest.mark.parametrize("views", [True, False])
-@pytest.mark.parametrize("W", [32, 96, 160, 192, 224])
-def test_every_width_that_is_a_multiple_of_32(W, views):
-    """--netwidth takes any value (config.py:20-27); every multiple of 32 up to 256 runs on the fused f32 kernels -- the
-    view layer's W/2 outputs in whole tiles, zero-padded when W/2 is not a multiple of 32 (W = 96, 160, 224): the query on
+@pytest.mark.parametrize("W", [32, 96, 160, 192, 224, 100, 65, 250, 6])
+def test_every_width_up_to_256(W, views):
+    """--netwidth takes any value (config.py:20-27); every width up to 256 runs on the fused f32 kernels in whole 32-channel
+    tiles -- zero-padded in the packed weights when W is not a multiple of 32 (W = 100, 65, 250, 6), as the view layer's
+    W/2 outputs are when W/2 is not (W = 96, 160, 224): the query on
     raw points and on embedded rows against the oracle (2e-5 of scale), every parameter gradient against float64 autograd
     (2e-3 of its scale), bitwise repeatable, and NeRF._composed (the GPU torch composition) is never reached."""
     from nerf_amd.network import NeRF

@@ -234,9 +234,9 @@ def test_query_repack_after_update(ops, gold):
 
 
 def test_unsupported_shapes_fail_loudly(ops):
-    sd = fx.make_nerf_state(1, W=100, D=2, skips=())
-    with pytest.raises(RuntimeError, match="multiple of 32"):
-        _packed(ops, sd, W=100, D=2, skips=())
+    sd = fx.make_nerf_state(1, W=300, D=2, skips=())
+    with pytest.raises(RuntimeError, match="W must be"):
+        _packed(ops, sd, W=300, D=2, skips=())
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ops.sample_coarse(torch.zeros(4, 8), 8)
 

@@ -98,11 +98,11 @@ def test_create_dnerf_wiring_and_best_checkpoint(tmp_path):
     assert torch.equal(tr2['network_fn']._time_out.bias, model._time_out.bias)
 
 
-@pytest.mark.parametrize("kw", [dict(netwidth=100, netwidth_fine=100), dict(multires=12, multires_views=5),
-                                dict(netwidth=100, netwidth_fine=128, use_viewdirs=False)])
+@pytest.mark.parametrize("kw", [dict(netwidth=300, netwidth_fine=300), dict(multires=12, multires_views=5),
+                                dict(netwidth=300, netwidth_fine=128, use_viewdirs=False)])
 def test_architectures_outside_the_kernels_ranges_still_run(tmp_path, kw):
-    """The reference's parser allows any --netwidth / --multires (model.py:11-34); the fused kernels take W a multiple of 32 up to
-    256 and multires <= 10.  Outside that, create_nerf's networks run the same arithmetic as a GPU torch
+    """The reference's parser allows any --netwidth / --multires (model.py:11-34); the fused kernels take W <= 256
+    (zero-padded to whole 32-channel tiles) and multires <= 10.  Outside that, create_nerf's networks run the same arithmetic as a GPU torch
     composition (announced by a warning) instead of refusing: render + a training step work, and a supported net beside
     them still takes the fused route."""
     from nerf_amd.model import create_nerf

@@ -53,8 +53,10 @@ def test_kernel_shape_reasons():
     import nerf_amd.vanilla_dynamic as vd
     assert NeRF(8, 256, 63, 27, 4, [4], True).kernel_shape_reason() is None
     assert NeRF(2, 64, 63, 27, 4, [], True).kernel_shape_reason(embedded_rows=True) is None
-    assert "W = 100" in NeRF(8, 100, 63, 27, 4, [4], True).kernel_shape_reason()
-    assert NeRF(8, 96, 63, 27, 4, [4], True).kernel_shape_reason() is None        # any multiple of 32 up to 256 is fused
+    assert "W = 300" in NeRF(8, 300, 63, 27, 4, [4], True).kernel_shape_reason()
+    assert NeRF(8, 96, 63, 27, 4, [4], True).kernel_shape_reason() is None        # any width up to 256 is fused (whole
+    assert NeRF(8, 100, 63, 27, 4, [4], True).kernel_shape_reason() is None       # 32-channel tiles, zero-padded)
+    assert "LayerNorm" in vd.NeRF(8, 96, 63, 27, 4, [4], True, use_layernorm=True).kernel_shape_reason()
     assert "D = 17" in NeRF(17, 128, 63, 27, 4, [4], True).kernel_shape_reason()
     assert "output_ch = 9" in NeRF(4, 128, 63, 0, 9, [2], False).kernel_shape_reason()
     assert NeRF(4, 128, 75, 33, 4, [2], True).kernel_shape_reason() is None                  # raw points: the encoder decides

@@ -118,10 +118,10 @@ def test_static_backward_rejects_what_does_not_fit():
         assert rc == 2      # NRF_ERR_UNSUPPORTED, nothing launched
         msg = lib.nrf_last_error_string().decode()
         assert "static scratch" in msg and "at most 3040 points" in msg, msg
-    # a shape the backward kernels do not take (W not a multiple of 32) is refused as such, whatever its size
+    # a shape the backward kernels do not take (W beyond 256) is refused as such, whatever its size
     bad = _lib.NrfNet()
     C.memmove(C.byref(bad), C.byref(pk.net), C.sizeof(bad))
-    bad.W = 100
+    bad.W = 300
     rc = lib.nrf_query_bwd_static(C.byref(bad), C.byref(pk.emb), ops._ptr(pk.packed), ops._ptr(dummy), ops._ptr(dummy), 64,
                                   C.byref(gs), C.c_void_p(0))
     assert rc == 2 and "unsupported network shape" in lib.nrf_last_error_string().decode()
