@@ -102,7 +102,7 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
         achieved = (pts / world) * STEP_FLOP_PER_POINT * args.steps / dt / 1e12      # per GPU: the roofline is one GPU's
         # bf16x3 issues three bf16 MFMAs per f32 product: in f32-equivalent FLOP/s its matrix roofline is a third of the bf16 peak
         peak = PEAK_F32_MFMA_TFLOPS if tprec == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3
-        traffic = step_traffic("train" if tprec == "fp32" else "train_bf16x3")
+        traffic = step_traffic({"fp32": "train", "bf16x3": "train_bf16x3"}.get(tprec, "train_" + tprec))
         out = {
             "metric": "rays/sec at 64+128 samples/ray (train step)",
             "value": n_global * args.steps / dt,
@@ -119,7 +119,7 @@ def run_train(args, torch, dist, world, rank, device, emit=True):
                          "hbm_frac_of_8TBs": (traffic / (dt / args.steps) / 8e12) if traffic and world == 1 else None,
                          "kernel": ("whole step (query_fwd<train> + dgrad + wgrad kernels)" if tprec == "fp32" else
                                     "whole step (query_fwd_bf16x3<train> + dgrad_x3 + wgrad<x3> kernels; FLOP/s f32-equivalent, "
-                                    "peak = bf16 peak / 3)") + ", per GPU; algorithmic 3.489 MFLOP/point over wall time; "
+                                    "peak = bf16 peak / 3" + ("; activations saved as f16" if tprec.endswith("a16") else "") + ")") + ", per GPU; algorithmic 3.489 MFLOP/point over wall time; "
                                    "traffic = HBM bytes per 4096-ray STEP over all kernels"},
         }
         out.update(mg)

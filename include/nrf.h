@@ -26,7 +26,7 @@ extern "C" {
 
 /* bumped whenever a struct layout or a signature changes (200: nrf_net_t carries the LayerNorm parameters); a binding
  * compares nrf_version() with the NRF_VERSION it was written against before passing structs */
-#define NRF_VERSION 220
+#define NRF_VERSION 230
 #define NRF_MAX_D 16
 
 typedef enum {
@@ -288,6 +288,21 @@ int nrf_mlp_bf16x3_bwd_pack_weights(const nrf_net_t *net, const nrf_embed_t *emb
 int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const void *packed_bwd_x3,
                          const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                          const nrf_net_t *grads, const float *pts, float *g_pts, void *stream);
+
+/* The bf16x3 training pass with the saved activations in f16 ("bf16x3_a16"; no counterpart in the reference): the step is
+ * bound by the bytes of its workspaces, and the post-ReLU activations are what the forward writes and
+ * the weight-gradient GEMMs read back.  nrf_query_fwd_train_bf16x3_a16 saves them (and the encoded inputs) as f16 --
+ * round-to-nearest, saturating at 65504; same element order, two bytes a value, inside a workspace of the usual
+ * nrf_train_acts_floats size -- and nrf_query_bwd_bf16x3_a16 (parameter gradients; `packed_bwd_x3` required) reads them as
+ * exact hi + lo bf16 pairs.  Gradient blocks stay f32.  Forward results are those of nrf_query_fwd_train_bf16x3 bit for bit;
+ * weight gradients carry the activations' f16 rounding (2^-12 per value: ~2e-4 of a gradient's norm against 2e-3, the
+ * bar every training arithmetic is tested to).  Static nets, W = 128 / 256, embed mode 0. */
+int nrf_query_fwd_train_bf16x3_a16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                   const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
+                                   void *stream);
+int nrf_query_bwd_bf16x3_a16(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const void *packed_bwd_x3,
+                             const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
+                             const nrf_net_t *grads, void *stream);
 
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */

@@ -30,7 +30,7 @@ class NrfEmbed(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 220     # include/nrf.h NRF_VERSION
+ABI_VERSION = 230     # include/nrf.h NRF_VERSION
 
 _SIGS = {
     "nrf_version": (C.c_int, []),
@@ -65,6 +65,10 @@ _SIGS = {
                                              vp, vp]),
     "nrf_query_bwd_bf16x3": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, vp, C.c_int64,
                                        C.POINTER(NrfNet), vp, vp, vp]),
+    "nrf_query_fwd_train_bf16x3_a16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, C.c_int64, C.c_int32, vp,
+                                                 vp, vp]),
+    "nrf_query_bwd_bf16x3_a16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, vp, C.c_int64,
+                                           C.POINTER(NrfNet), vp]),
     "nrf_mlp_bf16x3_bwd_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_mlp_bf16x3_bwd_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_mlp_bf16x3_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),

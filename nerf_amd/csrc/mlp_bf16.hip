@@ -777,9 +777,39 @@ __device__ __forceinline__ void store_tile_t8_quads(__amdgpu_buffer_rsrc_t rsrc,
     }
 }
 
+// The same tile as f16 (TrainLayout::half_acts, training mode "a16"): after the quad transpose a lane's four consecutive
+// points of one channel are two packed f16 pairs -- one 8-byte store.  nonneg: the values went through a ReLU, so the
+// saturation at 65504 (an infinity among the saved activations would turn a weight gradient into NaN) is one unsigned
+// 16-bit min per pair; the one section without a ReLU (feature_linear) clamps in f32 first.
+__device__ __forceinline__ void store_tile_t8_quads_h(__amdgpu_buffer_rsrc_t rsrc, int lane, int C, uint32_t sec, int t,
+                                                      const float (&r)[16], bool nonneg) {
+    const int q = lane & 31, h = lane >> 5;
+    const int voff = (((q >> 3) * C + 4 * h + (q & 3)) * 8 + (q & 4)) * 2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t a[4] = {__float_as_uint(r[4 * g]), __float_as_uint(r[4 * g + 1]), __float_as_uint(r[4 * g + 2]),
+                         __float_as_uint(r[4 * g + 3])};
+        quad_transpose(a, lane);
+        uint32_t p0, p1;
+        if (nonneg) {
+            p0 = sat2h(pack2h(__uint_as_float(a[0]), __uint_as_float(a[1])));
+            p1 = sat2h(pack2h(__uint_as_float(a[2]), __uint_as_float(a[3])));
+        } else {
+            p0 = pack2h(__builtin_amdgcn_fmed3f(__uint_as_float(a[0]), -65504.0f, 65504.0f),
+                        __builtin_amdgcn_fmed3f(__uint_as_float(a[1]), -65504.0f, 65504.0f));
+            p1 = pack2h(__builtin_amdgcn_fmed3f(__uint_as_float(a[2]), -65504.0f, 65504.0f),
+                        __builtin_amdgcn_fmed3f(__uint_as_float(a[3]), -65504.0f, 65504.0f));
+        }
+        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+        const u32x2s v = {p0, p1};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, (int)(sec * 4 + (32 * t + 8 * g) * 8 * 2), 0);
+    }
+}
+
 // sec: T8 section (floats from the tile base) the f32 values are saved to; gate_slot >= 0: also the ReLU gate bits
 // (bit order of store_gate_bits).  The stores sit in the conversion phase, where the matrix pipe is idle anyway.
-template <int NT, bool TRAIN = false>
+// TRAIN: 0 inference, 1 save f32 (the exact kernels' workspace format), 2 save f16 (half_acts)
+template <int NT, int TRAIN = 0>
 __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&acc)[NT], bool relu,
                                              const X3Save *sv = nullptr, uint32_t sec = 0, int gate_slot = -1) {
     uint32_t gm[4] = {0u, 0u, 0u, 0u};
@@ -802,8 +832,10 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
         }
         if constexpr (TRAIN) {
 #if NRF_X3_QUAD_STORES
-            store_tile_t8_quads(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r);
+            if constexpr (TRAIN == 2) store_tile_t8_quads_h(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r, relu);
+            else store_tile_t8_quads(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r);
 #else
+            static_assert(TRAIN != 2, "the f16 workspace is written by the quad stores");
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), sv->tb.rsrc, voff,
@@ -871,12 +903,12 @@ __device__ __forceinline__ void fill_pe3_x3(u32x4v (&oh)[KS], u32x4v (&ol)[KS], 
 // steps: steps 6j..6j+5 = sin(xyz), cos(xyz) of frequency 2j + h, step KS32-2 = x | y, step KS32-1 = z | pad), from the
 // slot-ordered values of fill_pe3_x3_v (slot 2 + 6j + r <-> step 6j + r: both lists give lane half h the frequencies 2j + h).
 // Frequencies >= L are stored as computed: the weight-gradient unpack drops those columns (blk_chan returns -1).
-template <int KS, int KS32>
+template <int KS, int KS32, bool HALF = false>
 __device__ __forceinline__ void save_pe3_t8(const X3Save &sv, uint32_t sec, const float (&v)[8 * KS], float x, float y, float z) {
     constexpr int NF = (8 * KS - 2) / 6;
     static_assert(6 * NF <= KS32 - 2, "the f32 k-step list must hold every frequency pair");
     const int h = sv.tb.h;
-    const int voff = ((sv.tb.m * (2 * KS32) + h) * 8 + sv.tb.q7) * 4;
+    const int voff = ((sv.tb.m * (2 * KS32) + h) * 8 + sv.tb.q7) * (HALF ? 2 : 4);
     asm volatile("" : "+s"(sec));
 #pragma unroll
     for (int st = 0; st < KS32; ++st) {
@@ -884,12 +916,16 @@ __device__ __forceinline__ void save_pe3_t8(const X3Save &sv, uint32_t sec, cons
         if (st < 6 * NF) val = v[2 + st];
         else if (st == KS32 - 2) val = h ? y : x;
         else if (st == KS32 - 1) val = h ? 0.0f : z;
+        if constexpr (HALF)     // encoder values lie in [-1, 1], raw coordinates are scene-sized: no saturation needed
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2h(val, 0.0f) & 0xffffu), sv.tb.rsrc, voff,
+                                                  (int)(sec * 4 + 2 * st * 8 * 2), 0);
+        else
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), sv.tb.rsrc, voff, (int)((sec + 2 * st * 8) * 4), 0);
     }
 }
 
 // Trunk of one net in bf16x3: layer 0 on S0 encoded k-steps (B0h, B0l), then the hidden layers.
-template <int NT, int S0, bool TRAIN = false, class B0H, class B0L>
+template <int NT, int S0, int TRAIN = 0, class B0H, class B0L>
 __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
                                             const u32x4v (&xh)[kBfKsX], const u32x4v (&xl)[kBfKsX], const u32x4v &one,
                                             const u32x4v &none, WStreamX3 &st, int n_trunk, int skip_in_mask, B0H &&b0h,
@@ -907,12 +943,12 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
             gemm_layer_x3<NT, 2 * NT + 1, true, kSt>(
                 acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
                 [&](int s) { return s < 2 * NT ? as_bf(hl[s < 2 * NT ? s : 0]) : as_bf(none); });
-        pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk + l * (32 * 32 * NT), a_mask + l * 256);
+        pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk + l * ((TRAIN == 2 ? 16 : 32) * 32 * NT), a_mask + l * 256);
     }
 }
 
 // View-direction head in bf16x3 (network.py:56-65) -> (rgb, alpha) of the wave's point tile, stored by lane half 0.
-template <int NT, bool TRAIN = false>
+template <int NT, int TRAIN = 0>
 __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
                                                  const u32x4v (&dh)[kBfKsD], const u32x4v (&dl)[kBfKsD], const u32x4v &one,
                                                  const u32x4v &none, WStreamX3 &st, const float *hb, int64_t pp,
@@ -938,7 +974,7 @@ __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)
                                                           acc1[0][2] + hb[kHbRgb + 2], alpha);
 }
 
-template <int NT, bool VIEWS, bool TRAIN = false>
+template <int NT, bool VIEWS, int TRAIN = 0>
 __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
@@ -978,7 +1014,7 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
                 if constexpr (TRAIN) {
                     float v[8 * kBfKsD];
                     fill_pe3_x3_v<kBfKsD>(dh, dl, v, d[0], d[1], d[2], h);
-                    save_pe3_t8<kBfKsD, kKsD>(sv, (uint32_t)a.tl.a_din, v, d[0], d[1], d[2]);
+                    save_pe3_t8<kBfKsD, kKsD, TRAIN == 2>(sv, (uint32_t)a.tl.a_din, v, d[0], d[1], d[2]);
                 } else {
                     fill_pe3_x3<kBfKsD>(dh, dl, d[0], d[1], d[2], h);
                 }
@@ -986,7 +1022,7 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
             if constexpr (TRAIN) {
                 float v[8 * kBfKsX];
                 fill_pe3_x3_v<kBfKsX>(xh, xl, v, q[0], q[1], q[2], h);
-                save_pe3_t8<kBfKsX, kKsX>(sv, (uint32_t)a.tl.a_xin, v, q[0], q[1], q[2]);
+                save_pe3_t8<kBfKsX, kKsX, TRAIN == 2>(sv, (uint32_t)a.tl.a_xin, v, q[0], q[1], q[2]);
             } else {
                 fill_pe3_x3<kBfKsX>(xh, xl, q[0], q[1], q[2], h);
             }
@@ -1683,7 +1719,7 @@ extern "C" int nrf_mlp_bf16x3_pack_weights(const nrf_net_t *net, const nrf_embed
 
 static int query_fwd_x3_impl(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
                              const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw, float *acts,
-                             void *stream, const char *who) {
+                             void *stream, const char *who, int half_acts = 0) {
     NRF_REQUIRE(net && emb, "%s: null descriptor", who);
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && pts && raw, "%s: null pointer", who);
     NRF_REQUIRE(n_points >= 0, "%s: negative n_points", who);
@@ -1708,19 +1744,23 @@ static int query_fwd_x3_impl(const nrf_net_t *net, const nrf_embed_t *emb, const
     for (int i = 1; i < net->D; ++i) if ((net->skips_mask >> (i - 1)) & 1) a.skip_in_mask |= 1 << i;
     a.use_viewdirs = net->use_viewdirs; a.output_ch = net->output_ch;
     a.acts = acts;
-    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, 0, half_acts);
     const int64_t ntiles = (n_points + 127) / 128;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);
     hipStream_t st = as_stream(stream);
-    switch (net->W / 32 + (net->use_viewdirs ? 0 : 100) + (acts ? 1000 : 0)) {
+    switch (net->W / 32 + (net->use_viewdirs ? 0 : 100) + (acts ? (half_acts ? 2000 : 1000) : 0)) {
         case 8: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a); break;
         case 108: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a); break;
         case 4: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a); break;
         case 104: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a); break;
-        case 1008: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true, true>), dim3(blocks), dim3(256), 0, st, a); break;
-        case 1108: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false, true>), dim3(blocks), dim3(256), 0, st, a); break;
-        case 1004: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, a); break;
-        case 1104: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1008: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1108: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1004: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1104: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 2008: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, true, 2>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 2108: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<8, false, 2>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 2004: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, true, 2>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 2104: hipLaunchKernelGGL((query_fwd_bf16x3_kernel<4, false, 2>), dim3(blocks), dim3(256), 0, st, a); break;
     }
     return check_launch(who);
 }
@@ -1736,6 +1776,16 @@ extern "C" int nrf_query_fwd_train_bf16x3(const nrf_net_t *net, const nrf_embed_
     NRF_REQUIRE(acts || n_points == 0, "nrf_query_fwd_train_bf16x3: acts workspace is null");
     return query_fwd_x3_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream,
                              "nrf_query_fwd_train_bf16x3");
+}
+
+/* The same forward saving its activations as f16 (TrainLayout::half_acts; training mode "bf16x3_a16"): the workspace has the
+ * size nrf_train_acts_floats gives, half of it is used; nrf_query_bwd_bf16x3_a16 consumes it. */
+extern "C" int nrf_query_fwd_train_bf16x3_a16(const nrf_net_t *net, const nrf_embed_t *emb, const void *packed, const float *pts,
+                                              const float *viewdirs, int64_t n_points, int32_t pts_per_ray, float *raw,
+                                              float *acts, void *stream) {
+    NRF_REQUIRE(acts || n_points == 0, "nrf_query_fwd_train_bf16x3_a16: acts workspace is null");
+    return query_fwd_x3_impl(net, emb, packed, pts, viewdirs, n_points, pts_per_ray, raw, acts, stream,
+                             "nrf_query_fwd_train_bf16x3_a16", 1);
 }
 
 extern "C" int64_t nrf_mlp_bf16x3_bwd_packed_bytes(const nrf_net_t *net, const nrf_embed_t *emb) {
@@ -1762,14 +1812,14 @@ extern "C" int nrf_mlp_bf16x3_bwd_pack_weights(const nrf_net_t *net, const nrf_e
 namespace nrf {
 int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
                     const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
-                    hipStream_t st) {
+                    hipStream_t st, int half_acts) {
     if (bf_check_net(net, emb, false) || net->D < 2) return NRF_ERR_UNSUPPORTED;
     BfPlan P;
     P.split = 1;
     bf_plan_net_bwd(P, net);
     DgradX3Args a{};
     a.plan = plan;
-    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs);
+    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, 0, half_acts);    // the chain reads the gate bits only
     a.packed = packed; a.stream = (const char *)packed_bwd_x3; a.stream_bytes = P.bytes;
     a.g_raw = g_raw; a.acts = acts; a.gbuf = gbuf; a.n_points = n_points;
     const int64_t ntiles = (n_points + 127) / 128;

@@ -136,7 +136,7 @@ __device__ __forceinline__ void ln_bwd(f32x16 (&g)[NT], const TBuf &ta, const TB
 
 int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
                     const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
-                    hipStream_t st);      // mlp_bf16.hip
+                    hipStream_t st, int half_acts);      // mlp_bf16.hip
 
 struct DgradArgs {
     NetPlan plan;
@@ -405,7 +405,26 @@ __device__ __forceinline__ void wg_split(const f32x4 &p0, const f32x4 &p1, WgFra
     }
 }
 
-template <int NA, int KA, class Req>
+// the same from eight f16 values (TrainLayout::half_acts): an f16 is exactly hi + lo (11 significant bits)
+typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+// (p BY VALUE, from a local copy of the LDS read: with `const u32x4 &p` bound to `*reinterpret_cast<const u32x4 *>(lds + ..)`
+// the compiler read ONE dword per fragment and used it for all four -- every weight gradient off by O(1), found with delta
+// patterns in a crafted workspace.)
+__device__ __forceinline__ void wg_split_h(const u32x4 p, WgFrag &f) {
+    const uint32_t pw[4] = {p[0], p[1], p[2], p[3]};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const wg_f32x2 v = __builtin_convertvector(__builtin_bit_cast(wg_f16x2, pw[w]), wg_f32x2);
+        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wg_bf16x2));
+        const float ra = v[0] - __uint_as_float(hi << 16), rb = v[1] - __uint_as_float(hi & 0xffff0000u);
+        f.hi[w] = hi;
+        f.lo[w] = __builtin_bit_cast(uint32_t, __builtin_convertvector((wg_f32x2){ra, rb}, wg_bf16x2));
+    }
+}
+
+// XH: the X operand's sections hold f16 (a tile's piece of one 8-point group is 512 bytes: 32 channels x 8 points, and a
+// lane's fragment is ONE 16-byte read); G stays f32.
+template <int NA, int KA, bool XH, class Req>
 __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
                                                int64_t nsteps, Req &&request) {
     static_assert(kWgM == 2, "the bf16x3 step covers one 32x32x16 MFMA: two 8-point groups");
@@ -423,9 +442,14 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
         }
 #pragma unroll
         for (int y = 0; y < KA; ++y) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
-            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024 + 512);
-            wg_split(p0, p1, B[y]);
+            if constexpr (XH) {
+                const u32x4 raw = *reinterpret_cast<const u32x4 *>(base + 8192 + (kt0 + y) * 512);
+                wg_split_h(raw, B[y]);
+            } else {
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
+                const f32x4 p1 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024 + 512);
+                wg_split(p0, p1, B[y]);
+            }
         }
     };
     auto land = [&]() {
@@ -465,7 +489,7 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
             // scheduler built one of the two unrolled steps as 36 MFMAs in a row with the whole split after the barrier
             // (matrix pipe idle for ~250 VALU ops).  Pin the shape: the 16 LDS reads first, then per MFMA its share of the
             // ~190 VALU ops.
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NA + KA), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA + (XH ? 1 : 2) * KA, 0);
 #pragma unroll
             for (int i = 0; i < 3 * NA * KA; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -489,7 +513,7 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
     }
 }
 
-template <bool X3>
+template <bool X3, bool XH = false>
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
     // The argument block is indexed by a block-uniform value: read it where it lies, in the kernel-argument segment
@@ -561,6 +585,22 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
                                                              16, lane_src,
                                                              (((m0 + mm) * a.Cg + 32 * (nsb * 8 + i)) * 8) * 4, 0, 0);
+            } else if (XH) {
+                // f16 X sections: one 1 KiB copy = TWO adjacent 32-channel tiles of one 8-point group (64 channels x 16 bytes;
+                // lanes beyond the section read zeros or a tile no fragment uses)
+                const int j = i - 8;
+                if (i >= 8 && 2 * j < xn) {
+                    const int kt = ksb * 8 + 2 * j;
+                    const int sec = kt >= a.k_tiles0;
+                    const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
+                    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(acts) + tile * a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 2, 0x00020000);
+                    char *dx = lds + stage * kWgStage + 8192 + j * 1024;
+#pragma unroll
+                    for (int mm = 0; mm < kWgM; ++mm)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dx + mm * 16384),
+                                                                 16, lane * 16, (((m0 + mm) * a.Ca[sec] + c0) * 8) * 2, 0, 0);
+                }
             } else if (i - 8 < xn && i >= 8) {
                 const int kt = ksb * 8 + (i - 8);
                 const int sec = kt >= a.k_tiles0;
@@ -578,7 +618,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     // exact wait counts); waves of one workgroup may run different instances, all with the same barrier sequence.
     auto run = [&](auto na_c, auto ka_c) {
         constexpr int NA = decltype(na_c)::value, KA = decltype(ka_c)::value;
-        if constexpr (X3) wgrad_steps_x3<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        if constexpr (X3) wgrad_steps_x3<NA, KA, XH>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
         else wgrad_steps<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
     };
     auto pick_k = [&](auto na_c) {
@@ -759,6 +799,7 @@ struct Bwd {
     hipStream_t st;
     int64_t slab_off = 0, slab_cap = 0;    // floats: every GEMM gets its own region of `slab`
     bool x3 = false;                       // wgrad on the bf16 matrix pipe (three bf16 MFMAs per product)
+    bool xh = false;                       // x3 only: the activation sections hold f16 (TrainLayout::half_acts)
     ReduceBatch batch;
     int nbatch = 0, max_blocks = 1;
     WgradArgs wb{};
@@ -778,7 +819,8 @@ struct Bwd {
             wb.gbuf = gbuf; wb.acts = acts; wb.g_tile = tl.g_tile; wb.a_tile = tl.a_tile; wb.ntiles = ntiles;
             wb.chunk_tiles = chunk_tiles; wb.nchunks = nchunks;
             const unsigned blocks = (unsigned)npairs * (unsigned)nchunks;
-            if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, wb);
+            if (x3 && xh) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(blocks), dim3(256), 0, st, wb);
+            else if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, wb);
             else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, wb);
             nent = 0; npairs = 0;
             int rc = check_launch("nrf_query_bwd (wgrad)");
@@ -881,7 +923,7 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                           const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256,
-                          bool x3 = false, const void *packed_bwd_x3 = nullptr, bool straight = false) {
+                          bool x3 = false, const void *packed_bwd_x3 = nullptr, bool straight = false, bool half_acts = false) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
@@ -903,7 +945,10 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     const int nt = pl.nt, W = net->W, Wp = 32 * nt, D = net->D, ic = net->input_ch, icv = net->input_ch_views;
     hipStream_t st = as_stream(stream);
     DgradArgs d{};
-    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs, pl.layernorm);
+    if (half_acts && (!x3 || !packed_bwd_x3 || want_gx || straight || time_ch || pl.layernorm || emb->mode != 0))
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: the f16 activation workspace belongs to the static nets' bf16x3 "
+                         "training kernels (parameter gradients only)");
+    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs, pl.layernorm, half_acts);
     d.packed = packed; d.g_raw = g_raw; d.acts = acts; d.gbuf = gbuf; d.n_points = n_points;
     const int64_t ntiles = (n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
@@ -912,7 +957,9 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     // the chain on the bf16 matrix pipe, where a kernel exists: static nets, and the deformation net (its chain ends at its
     // own parameters: nothing downstream amplifies the 1e-5 of this arithmetic, unlike the canonical net's d/dx)
     if (x3 && packed_bwd_x3 && !want_gx && !straight)
-        x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st);
+        x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st, half_acts);
+    if (half_acts && x3rc != NRF_OK)
+        return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_bf16x3_a16: this shape has no bf16x3 kernels (W = 128, 256; D >= 2)");
     if (x3rc != NRF_OK && x3rc != NRF_ERR_UNSUPPORTED) return x3rc;
     if (x3rc == NRF_OK) goto dgrad_done;
     if (pl.layernorm) {
@@ -957,7 +1004,7 @@ dgrad_done:
 
     Bwd B{};
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
-    B.ntiles = ntiles; B.st = st; B.x3 = x3;
+    B.ntiles = ntiles; B.st = st; B.x3 = x3; B.xh = half_acts;
     B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, max_chunks);
     B.slab_cap = slab_floats(net, n_points, max_chunks) - ln_partial_floats(net);
     if (pl.layernorm) {   // the affine parameters' gradients: independent of the weight-gradient GEMMs below
@@ -984,6 +1031,7 @@ dgrad_done:
         if (rc) return rc;
     }
     const TrainLayout &tl = d.tl;
+    const int pp = tl.half_acts ? 16 : 32;             // floats per channel of an activation section (f16: two bytes a value)
     const int xk = 2 * kKsX / 32, dk = 2 * kKsD / 32;  // 32-channel tiles of the k-space input blocks
     const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};
     for (int l = 0; l < D; ++l) {
@@ -1000,7 +1048,7 @@ dgrad_done:
             parts[np++] = Xin;
             if (time_ch) parts[np++] = Tin;   // columns fed by gamma(t) (vanilla_dynamic/network.py:296, :176)
         } else {
-            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * 32 * Wp, Wp, nt, BLK_HIDDEN, 0, 0, W, skip ? skip_ch : 0};
+            parts[np++] = Bwd::XPart{tl.a_trunk + (int64_t)(l - 1) * pp * Wp, Wp, nt, BLK_HIDDEN, 0, 0, W, skip ? skip_ch : 0};
             if (skip) parts[np++] = Xin;   // network.py:52-53: cat[input_pts, h]
         }
         rc = B.run(gsec, Wp, nt, parts, np, ld, &dst, 1);
@@ -1011,7 +1059,7 @@ dgrad_done:
             if (rc) return rc;
         }
     }
-    const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * 32 * Wp;
+    const int64_t a_last = tl.a_trunk + (int64_t)(D - 1) * pp * Wp;
     const Bwd::XPart Hlast{a_last, Wp, nt, BLK_HIDDEN, 0, 0, W, 0};
     if (pl.use_viewdirs) {
         NRF_REQUIRE(grads->feature_w && grads->feature_b && grads->alpha_w && grads->alpha_b && grads->views_w &&
@@ -1058,6 +1106,17 @@ extern "C" int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb
     NRF_REQUIRE((pts == nullptr) == (g_pts == nullptr), "nrf_query_bwd_bf16x3: pts and g_pts go together");
     return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, pts, g_pts, stream, 256, true,
                           packed_bwd_x3);
+}
+
+/* nrf_query_bwd_bf16x3 for a workspace nrf_query_fwd_train_bf16x3_a16 wrote (activations saved as f16): the weight-gradient
+ * GEMMs read half the bytes for their X operand.  Parameter gradients of static nets; weight gradients then carry the
+ * activations' f16 rounding (2^-12 relative per value: ~2e-4 of a gradient's norm, the gradient tests' bar is 2e-3). */
+extern "C" int nrf_query_bwd_bf16x3_a16(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed,
+                                        const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf,
+                                        float *slab, int64_t n_points, const nrf_net_t *grads, void *stream) {
+    NRF_REQUIRE(packed_bwd_x3, "nrf_query_bwd_bf16x3_a16: packed_bwd_x3 is null");
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, nullptr, nullptr, stream, 256, true,
+                          packed_bwd_x3, false, true);
 }
 
 extern "C" int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,

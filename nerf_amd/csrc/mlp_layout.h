@@ -108,7 +108,10 @@ struct NetPlan {
 // weight-gradient GEMM -- which contracts over POINTS -- reads whole 1 KiB pieces of it as MFMA operands
 // (lane (s, c) takes the 4 points 8m+4s.. of channel c).
 struct TrainLayout {
-    int32_t nt, n_trunk, use_viewdirs, pad_;
+    int32_t nt, n_trunk, use_viewdirs;
+    int32_t half_acts;               // 1: the activation sections (inputs, trunk, feature, view layer) hold f16 values -- same
+                                     // element order, two bytes each, so a section of C channels takes 16 * C floats (the
+                                     // bf16x3 training mode "a16": half the bytes the forward writes and wgrad reads back)
     // activations (floats from the tile's base)
     int64_t a_xin, a_din, a_tin;     // input blocks in k-step space: channel 2*step + half (64 / 32 / 24 ch)
     int64_t a_trunk;                 // D sections of W channels: post-ReLU outputs of trunk layer l
@@ -129,18 +132,20 @@ struct TrainLayout {
     int64_t g_tile;
 };
 
-NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs, int layernorm = 0) {
+NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs, int layernorm = 0, int half_acts = 0) {
     TrainLayout t{};
     t.nt = nt; t.n_trunk = D; t.use_viewdirs = use_viewdirs;
     const int W = 32 * nt;
     const int Wv = 32 * ((nt + 1) / 2);     // the view layer's W/2 outputs in whole 32-channel tiles (W = 96: 48 -> 64, zero-padded)
+    t.half_acts = half_acts;
+    const int pp = half_acts ? 16 : 32;     // floats per channel of a 32-point activation section
     int64_t c = 0;
-    t.a_xin = c; c += 32 * 2 * kKsX;
-    t.a_din = c; c += 32 * 2 * kKsD;
-    t.a_tin = c; c += 32 * 2 * kKsT;
-    t.a_trunk = c; c += (int64_t)32 * W * D;
-    t.a_feat = c; c += 32 * W;
-    t.a_hv = c; c += 32 * Wv;
+    t.a_xin = c; c += pp * 2 * kKsX;
+    t.a_din = c; c += pp * 2 * kKsD;
+    t.a_tin = c; c += pp * 2 * kKsT;
+    t.a_trunk = c; c += (int64_t)pp * W * D;
+    t.a_feat = c; c += pp * W;
+    t.a_hv = c; c += pp * Wv;
     t.a_mask = c; c += (int64_t)256 * (D + 1);
     t.a_xhat = t.a_xhat_v = t.a_rstd = -1;
     if (layernorm) {

@@ -29,11 +29,17 @@ class _QueryFunction(torch.autograd.Function):
         if need_grad:
             packed.refresh()                     # the backward reads this f32 copy (W^T blocks of the dgrad chain)
             fwd = packed
-            if module.train_precision == "bf16x3" and key[0] == 0 and module.W in (128, 256):
+            x3_shape = key[0] == 0 and module.W in (128, 256)
+            if module.train_precision in ("bf16x3", "bf16x3_a16") and x3_shape:
                 fwd = module._packed(key + ("bf16x3",))      # the forward alone runs on the bf16 matrix pipe
-            elif module.train_precision not in ("fp32", "bf16x3"):
-                raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', not {module.train_precision!r}")
-            raw, acts = fwd.query_train(pts, viewdirs, pts_per_ray)
+            elif module.train_precision not in ("fp32", "bf16x3", "bf16x3_a16"):
+                raise ValueError(f"train_precision must be 'fp32', 'bf16x3' or 'bf16x3_a16', not {module.train_precision!r}")
+            # "bf16x3_a16": the activations are saved as f16 (half the workspace bytes written and read back); needs the
+            # bf16x3 chain kernels (D >= 2) and parameter gradients only, otherwise plain bf16x3
+            a16 = (fwd is not packed and module.train_precision == "bf16x3_a16" and module.D >= 2
+                   and not pts.requires_grad)
+            raw, acts = fwd.query_train(pts, viewdirs, pts_per_ray, a16=True) if a16 else fwd.query_train(pts, viewdirs, pts_per_ray)
+            ctx.a16 = a16
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
             ctx.versions = packed._versions     # the dgrad chain reads the packed copy: it must still be this one
             ctx.x3 = fwd is not packed
@@ -57,7 +63,7 @@ class _QueryFunction(torch.autograd.Function):
             # w.r.t. the sample positions): nrf_query_bwd_input, the chain the deformation net's training uses
             grads, g_pts = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, pts=ctx.saved_tensors[1], x3=ctx.x3)
         else:
-            grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, x3=ctx.x3)
+            grads = packed.query_bwd(g_raw.contiguous(), ctx.n_points, acts, x3=ctx.x3, a16=ctx.a16)
         order = [name for name, _ in ctx.module.named_parameters()]
         return (None, None, g_pts, None, None, None) + tuple(grads.get(n) for n in order)
 
@@ -90,7 +96,9 @@ class NeRF(nn.Module):
         self.precision = "fp32"
         # arithmetic of queries that need gradients: "fp32" = exact f32 MFMA (the reference's arithmetic); "bf16x3" = the
         # training forward and weight-gradient GEMMs as three bf16 MFMAs per product on hi/residual operands (f32-grade:
-        # raw within 1e-5 of its scale, gradients within the same 2e-3 of the reference's autograd)
+        # raw within 1e-5 of its scale, gradients within the same 2e-3 of the reference's autograd); "bf16x3_a16" = the
+        # same with the saved activations in f16 (half the bytes of the step's largest workspace: weight gradients carry
+        # a 2^-12 rounding of the activations, ~2e-4 of their norm)
         self.train_precision = "fp32"
 
     # ------------------------------------------------------------------ packed weights

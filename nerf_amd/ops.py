@@ -286,9 +286,10 @@ class PackedNet:
               "nrf_query_fwd_train")
         return raw, acts
 
-    def query_bwd(self, g_raw, n_points, acts, pts=None, x3=False):
+    def query_bwd(self, g_raw, n_points, acts, pts=None, x3=False, a16=False):
         """-> dict name -> gradient tensor (same shapes as the parameters); with `pts` (the query points of the
-        forward) -> (that dict, d(loss)/d(pts) [P,3]).  x3: the weight-gradient GEMMs on the bf16x3 arithmetic."""
+        forward) -> (that dict, d(loss)/d(pts) [P,3]).  x3: the weight-gradient GEMMs on the bf16x3 arithmetic.
+        a16: `acts` holds f16 activations (PackedNetBf16x3.query_train(a16=True)); needs x3=True, parameters only."""
         g_raw = _f32(g_raw, "g_raw")
         dev = g_raw.device
         lib = _lib.lib()
@@ -319,6 +320,14 @@ class PackedNet:
                                                 _ptr(self.bwd_x3_stream() if x3 != "wgrad" else None), _ptr(g_raw),
                                                 _ptr(acts), _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()),
                   "nrf_dnerf_time_bwd_bf16x3")
+            return grads
+        if a16:
+            if not x3 or x3 == "wgrad" or pts is not None or self.bwd_x3_stream() is None:
+                raise RuntimeError("nerf_amd: the f16 activation workspace belongs to the bf16x3 training kernels of static "
+                                   "nets (W = 128, 256; parameter gradients only)")
+            check(lib.nrf_query_bwd_bf16x3_a16(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
+                                               _ptr(self.bwd_x3_stream()), _ptr(g_raw), _ptr(acts), _ptr(gbuf), _ptr(slab),
+                                               n_points, C.byref(gn), _stream()), "nrf_query_bwd_bf16x3_a16")
             return grads
         if x3:
             g_pts = None
@@ -634,9 +643,10 @@ class PackedNetBf16x3(PackedNetBf16):
               "nrf_query_fwd_bf16x3")
         return raw
 
-    def query_train(self, pts, viewdirs=None, pts_per_ray=1):
+    def query_train(self, pts, viewdirs=None, pts_per_ray=1, a16=False):
         """Training forward on the bf16x3 arithmetic -> (raw, acts); `acts` has the f32 kernels' layout, so the
-        backward entry points of the f32 PackedNet of the same module consume it."""
+        backward entry points of the f32 PackedNet of the same module consume it.  a16: the activations are saved as f16
+        (half the bytes; PackedNet.query_bwd(..., x3=True, a16=True) reads them)."""
         self.refresh()
         pts = _f32(pts, "pts")
         P = pts.shape[0]
@@ -645,7 +655,7 @@ class PackedNetBf16x3(PackedNetBf16):
         acts = torch.empty((max(n, 1),), device=pts.device, dtype=torch.float32)
         if viewdirs is not None:
             viewdirs = _f32(viewdirs, "viewdirs")
-        check(_lib.lib().nrf_query_fwd_train_bf16x3(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
-                                                    _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _ptr(acts), _stream()),
-              "nrf_query_fwd_train_bf16x3")
+        fn = "nrf_query_fwd_train_bf16x3_a16" if a16 else "nrf_query_fwd_train_bf16x3"
+        check(getattr(_lib.lib(), fn)(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(pts),
+                                      _ptr(viewdirs), P, int(pts_per_ray), _ptr(raw), _ptr(acts), _stream()), fn)
         return raw, acts

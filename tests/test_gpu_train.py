@@ -35,7 +35,8 @@ def make_nets(train_precision="fp32"):
 
 # the training kernels in the reference's f32 arithmetic, and on the bf16x3 arithmetic (three bf16 MFMAs per product on
 # hi/residual operands): both against the SAME reference autograd goldens and the same bars
-TRAIN_PRECISIONS = ["fp32", "bf16x3"]
+# "bf16x3_a16": bf16x3 with the saved activations in f16 (half the bytes of the step's largest workspace)
+TRAIN_PRECISIONS = ["fp32", "bf16x3", "bf16x3_a16"]
 
 
 def check_grads(net, gold, tag, tol):
@@ -261,6 +262,29 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
             sc = max(float(grads_a[k].abs().max()), 1e-12)
             e = float((grads_a[k] - grads_c[k]).abs().max())
             assert e <= 5e-5 * sc, (mode, k, e, sc)
+    # "a16": the same forward saving its activations as f16 (nrf_query_fwd_train_bf16x3_a16) -- raw bit for bit, the
+    # workspace the f32 one rounded to f16 (2^-11 relative, element order unchanged, half the floats per section), gate
+    # words identical; nrf_query_bwd_bf16x3_a16 then differs from nrf_query_bwd_bf16x3 on the f32 workspace by that
+    # rounding of the weight-gradient GEMMs' X operand alone: <= 1e-3 of each gradient's scale (measured ~2e-4)
+    raw_c, acts_c = x3.query_train(pts, dirs, ppr, a16=True)
+    assert torch.equal(raw_c, raw_b)
+    a_mask_h = a_mask // 2
+    tile_h = a_mask_h + 256 * (D + 1)
+    Cw = acts_c[:(P + 31) // 32 * tile_h].reshape(-1, tile_h)
+    fc = Cw[:n_full, :a_mask_h].contiguous().view(torch.float16).float()[:, keep]
+    assert float(((fc - fb).abs() * live).max()) <= 6e-4 * float(fb.abs().max())
+    assert torch.equal(Cw[:n_full, a_mask_h:].view(torch.int32)[:, :gb.shape[1]], gb)
+    grads_x3 = f32.query_bwd(g_raw, P, acts_b, x3=True)
+    grads_h = f32.query_bwd(g_raw, P, acts_c, x3=True, a16=True)
+    worst = 0.0
+    for k in grads_x3:
+        sc = max(float(grads_x3[k].abs().max()), 1e-12)
+        e = float((grads_x3[k] - grads_h[k]).abs().max()) / sc
+        worst = max(worst, e)
+        assert e <= 1e-3, (k, e)
+        if k.endswith("bias"):       # bias gradients are row sums of G alone: untouched by the activations' format
+            assert e <= 5e-5, (k, e)
+    print(f"a16 {cfg}: weight gradients within {worst:.1e} of their scale of the f32-workspace bf16x3 backward")
 
 
 @pytest.mark.parametrize("train_precision", TRAIN_PRECISIONS)
