@@ -45,7 +45,7 @@ def parse():
                     help="fp32 = the reference's arithmetic (the headline number); bf16 = the optional bf16 MFMA variant; "
                          "f16 = the same 16-bit kernel with f16 hidden operands (saturating)")
     ap.add_argument("--train-rays", type=int, default=4096, help="global ray batch of the train workload")
-    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3", "bf16x3_a16"],
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3", "bf16x3_a16", "bf16x3_w16"],
                     help="train workload: fp32 = the reference's arithmetic; bf16x3 = three bf16 MFMAs per f32 product "
                          "(f32-grade results, gradients within the same 2e-3 of the reference's autograd)")
     ap.add_argument("--n-importance", type=int, default=128,
@@ -345,6 +345,8 @@ def extras(args, torch, dist, device, coarse, fine, step, timer):
     also["train_step_bf16x3"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
     a.train_precision = "bf16x3_a16"      # the same with the saved activations in f16 (weight gradients within ~2e-4)
     also["train_step_bf16x3_a16"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
+    a.train_precision = "bf16x3_w16"      # that plus scaled f16 gradient blocks: weight-gradient GEMMs as single f16 MFMAs
+    also["train_step_bf16x3_w16"] = brief(bench_train.run_train(a, torch, dist, 1, 0, device, emit=False))
     a.train_precision = "fp32"
     a.steps, a.warmup = 2, 1
     for prec in ("fp32", "bf16", "bf16x3"):

@@ -304,6 +304,18 @@ int nrf_query_bwd_bf16x3_a16(const nrf_net_t *net, const nrf_embed_t *emb, const
                              const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                              const nrf_net_t *grads, void *stream);
 
+/* "bf16x3_w16" (no counterpart in the reference): the gradient blocks saved as f16 as well.  The activation-gradient chain
+ * (bf16x3 arithmetic, unchanged) runs on gradients scaled by the power of two that brings the pass's largest |g_raw| into
+ * [2^10, 2^11) -- the chain is linear, so this is what mixed-precision training calls loss scaling, decided per pass on the device --
+ * and saves its blocks as f16 (saturating at 65504); the weight-gradient GEMMs are then ONE f16 MFMA per tile pair on the two
+ * f16 workspaces (a third of the matrix work, no operand split, half the bytes on both sides) and the slab reduction undoes
+ * the scale exactly.  Forward: nrf_query_fwd_train_bf16x3_a16.  Weight and bias gradients carry a 2^-12 rounding of both
+ * operands: within ~1e-3 of their scale of the exact pass (the gradient tests' bar is 2e-3).  `slab` as nrf_train_slab_floats
+ * (its last 64 floats hold the scale's scalar). */
+int nrf_query_bwd_bf16x3_w16(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed, const void *packed_bwd_x3,
+                             const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
+                             const nrf_net_t *grads, void *stream);
+
 /* bf16 variant of K6 (BASELINE configs[4]: "deformation network ... bf16 MFMA path").  ONE weight stream holds both
  * nets (time net first); dx and x + dx stay in f32.  Same arguments / results as nrf_dnerf_query_fwd otherwise. */
 int64_t nrf_dnerf_bf16_packed_bytes(const nrf_net_t *time_net, const nrf_net_t *occ_net, const nrf_embed_t *emb);

@@ -69,6 +69,8 @@ _SIGS = {
                                                  vp, vp]),
     "nrf_query_bwd_bf16x3_a16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, vp, C.c_int64,
                                            C.POINTER(NrfNet), vp]),
+    "nrf_query_bwd_bf16x3_w16": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp, vp, vp, vp, vp, C.c_int64,
+                                           C.POINTER(NrfNet), vp]),
     "nrf_mlp_bf16x3_bwd_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),
     "nrf_mlp_bf16x3_bwd_pack_weights": (C.c_int, [C.POINTER(NrfNet), C.POINTER(NrfEmbed), vp, vp]),
     "nrf_mlp_bf16x3_packed_bytes": (C.c_int64, [C.POINTER(NrfNet), C.POINTER(NrfEmbed)]),

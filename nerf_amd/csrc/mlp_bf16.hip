@@ -1052,7 +1052,9 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
 // ---- bf16x3 activation-gradient chain (the dgrad_kernel of mlp_bwd.hip on the bf16 matrix pipe) ------------------------
 // A gradient block on its way from one GEMM of the chain to the next: accumulators (or VGPR values) [+ sc * head vector]
 // -> ReLU gate -> saved in f32 to its T8 section of `gbuf` (what the weight-gradient GEMMs read) -> hi/residual operands.
-template <int NT, bool FROM_ACC, bool GATE, bool AXPY>
+// G16 (training mode "w16"): the saved copy is f16 (the chain's gradients are pre-scaled by a power of two so that the
+// step's largest |d(loss)/d(raw)| is in [2^10, 2^11); saturating at 65504) -- the chain's own operands keep their hi/residual pair.
+template <int NT, bool FROM_ACC, bool GATE, bool AXPY, bool G16 = false>
 __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&src)[NT],
                                                const u32x4 &gate, const WBuf &wb, uint32_t vec, float sc, const TBuf &tg,
                                                uint32_t sec, int C) {
@@ -1086,8 +1088,10 @@ __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl
             }
         }
 #if NRF_X3_QUAD_STORES
-        store_tile_t8_quads(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r);
+        if constexpr (G16) store_tile_t8_quads_h(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r, false);
+        else store_tile_t8_quads(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r);
 #else
+        static_assert(!G16, "the f16 gradient workspace is written by the quad stores");
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), tg.rsrc, voff,
@@ -1104,7 +1108,22 @@ __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl
     }
 }
 
+// store_head_tile (mlp_device.h) into an f16 section
+__device__ __forceinline__ void store_head_tile_h(const TBuf &tb, uint32_t sec, int C, int c0, const float (&vals)[8], int n) {
+    const int voff = ((tb.m * C + c0 + 16 * tb.h) * 8 + tb.q7) * 2;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (tb.h == 0 && j == o && o < n) v = vals[o];
+        v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2h(v, 0.0f) & 0xffffu), tb.rsrc, voff, (int)(sec * 4 + j * 8 * 2), 0);
+    }
+}
+
 struct DgradX3Args {
+    const unsigned *gmax;    // G16: bits of the step's largest |g_raw| (gmax_kernel, mlp_bwd.hip); else unused
     NetPlan plan;            // head-vector offsets into the f32 packed buffer
     TrainLayout tl;
     const float *packed;     // nrf_mlp_pack_weights
@@ -1117,7 +1136,7 @@ struct DgradX3Args {
 
 // Autograd of network.py:46-69 w.r.t. every layer's pre-activations, written to `gbuf` exactly as dgrad_kernel writes it.
 // Four waves share the W^T stream through LDS (the machinery of the query kernels); a wave owns one 32-point tile.
-template <int NT, bool VIEWS>
+template <int NT, bool VIEWS, bool G16 = false>
 __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
     __shared__ __attribute__((aligned(1024))) char lds[kStages * kChunk];
     const NetPlan &pl = a.plan;
@@ -1137,6 +1156,11 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
     wb.h16 = (lane >> 5) * 16;
     const int64_t ntiles = (a.n_points + 127) >> 7, n32 = (a.n_points + 31) >> 5;
     const u32x4 nogate = {0u, 0u, 0u, 0u};
+    // G16: the whole chain runs on gradients scaled by gs = 2^-E, E the exponent of the step's largest |g_raw| (the chain is
+    // linear and a power of two commutes with every rounding in it); the reduction of the weight gradients divides by it
+    float gs = 1.0f;
+    constexpr int gpw = G16 ? 16 : 32;       // floats per channel of a gradient section
+    if constexpr (G16) gs = nrf_grad_scale(*a.gmax);
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // a wave whose 32-point tile lies beyond the workspaces still walks the stream (it is shared); zero-length
@@ -1151,9 +1175,11 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
         u32x4v hh[2 * NT], hl[2 * NT];
         u32x4 gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (pl.n_trunk - 1) * 256, lane);
         if constexpr (VIEWS) {
-            const float4 gr = live ? reinterpret_cast<const float4 *>(a.g_raw)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 gr = live ? reinterpret_cast<const float4 *>(a.g_raw)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (G16) { gr.x *= gs; gr.y *= gs; gr.z *= gs; gr.w *= gs; }
             const float hv3[8] = {gr.x, gr.y, gr.z, 0.f, 0.f, 0.f, 0.f, 0.f};
-            store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, hv3, 3);            // d/d(rgb logits): rgb_linear's wgrad
+            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_head, 32, 0, hv3, 3);
+            else store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, hv3, 3);            // d/d(rgb logits): rgb_linear's wgrad
             {   // through rgb_linear (network.py:64) and the view layer's ReLU: three-term sums, on the VALU in f32
                 f32x16 g2[NT / 2];
                 zero_acc<NT / 2>(g2);
@@ -1162,38 +1188,40 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
                 axpy_head<NT / 2>(g2, wb, (uint32_t)pl.rgb_vec + 2 * (NT / 2) * 32, gr.z);
                 const u32x4 hvgate = load_gate_bits(ta, (uint32_t)tl.a_mask + pl.n_trunk * 256, lane);
                 u32x4v vh[NT], vl[NT];
-                finish_grad_x3<NT / 2, false, true, false>(vh, vl, g2, hvgate, wb, 0u, 0.f, tg, (uint32_t)tl.g_hv, W / 2);
+                finish_grad_x3<NT / 2, false, true, false, G16>(vh, vl, g2, hvgate, wb, 0u, 0.f, tg, (uint32_t)tl.g_hv, W / 2);
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
                 gemm_layer_x3<NT, NT, false, x3_tile_stores(NT / 2)>(acc, st, [&](int s) { return as_bf(vh[s]); },
                                                                      [&](int s) { return as_bf(vl[s]); });
             }
-            finish_grad_x3<NT, true, false, false>(hh, hl, acc, nogate, wb, 0u, 0.f, tg, (uint32_t)tl.g_feat, W + 32);
+            finish_grad_x3<NT, true, false, false, G16>(hh, hl, acc, nogate, wb, 0u, 0.f, tg, (uint32_t)tl.g_feat, W + 32);
             const float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);          // d/d(alpha): alpha_linear's wgrad
+            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);
+            else store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);          // d/d(alpha): alpha_linear's wgrad
             // through feature_linear and alpha_linear (network.py:56-57) -> d/d(h_{D-1}), then that layer's ReLU
             gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT)>(acc, st, [&](int s) { return as_bf(hh[s]); },
                                                                  [&](int s) { return as_bf(hl[s]); });
-            finish_grad_x3<NT, true, true, true>(hh, hl, acc, gate, wb, (uint32_t)pl.alpha_vec, gr.w, tg,
-                                                 (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (32 * W), W);
+            finish_grad_x3<NT, true, true, true, G16>(hh, hl, acc, gate, wb, (uint32_t)pl.alpha_vec, gr.w, tg,
+                                                      (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (gpw * W), W);
         } else {
             float ho[8];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) ho[o] = (live && o < pl.output_ch) ? a.g_raw[p * pl.output_ch + o] : 0.0f;
-            store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
+            for (int o = 0; o < 8; ++o) ho[o] = (live && o < pl.output_ch) ? a.g_raw[p * pl.output_ch + o] * gs : 0.0f;
+            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
+            else store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
             f32x16 g[NT];
             zero_acc<NT>(g);
 #pragma unroll
             for (int o = 0; o < 8; ++o)
                 if (o < pl.output_ch) axpy_head<NT>(g, wb, (uint32_t)pl.out_vec + o * NT * 32, ho[o]);
-            finish_grad_x3<NT, false, true, false>(hh, hl, g, gate, wb, 0u, 0.f, tg,
-                                                   (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (32 * W), W);
+            finish_grad_x3<NT, false, true, false, G16>(hh, hl, g, gate, wb, 0u, 0.f, tg,
+                                                        (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (gpw * W), W);
         }
         // trunk in reverse (network.py:49-53): g_{l-1} = gate_{l-1} . (W_l[:, hidden]^T g_l)
         for (int l = pl.n_trunk - 1; l >= 1; --l) {
             gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);       // in flight during the GEMM
             gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT)>(acc, st, [&](int s) { return as_bf(hh[s]); },
                                                                  [&](int s) { return as_bf(hl[s]); });
-            finish_grad_x3<NT, true, true, false>(hh, hl, acc, gate, wb, 0u, 0.f, tg, (uint32_t)tl.g_trunk + (l - 1) * (32 * W), W);
+            finish_grad_x3<NT, true, true, false, G16>(hh, hl, acc, gate, wb, 0u, 0.f, tg, (uint32_t)tl.g_trunk + (l - 1) * (gpw * W), W);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests in flight must land before the LDS is released
@@ -1812,19 +1840,24 @@ extern "C" int nrf_mlp_bf16x3_bwd_pack_weights(const nrf_net_t *net, const nrf_e
 namespace nrf {
 int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
                     const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
-                    hipStream_t st, int half_acts) {
+                    hipStream_t st, int half_acts, const unsigned *gmax) {
     if (bf_check_net(net, emb, false) || net->D < 2) return NRF_ERR_UNSUPPORTED;
     BfPlan P;
     P.split = 1;
     bf_plan_net_bwd(P, net);
     DgradX3Args a{};
     a.plan = plan;
-    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, 0, half_acts);    // the chain reads the gate bits only
+    a.tl = make_train_layout(net->W / 32, net->D, net->use_viewdirs, 0, half_acts, gmax != nullptr);    // reads the gate bits only
+    a.gmax = gmax;
     a.packed = packed; a.stream = (const char *)packed_bwd_x3; a.stream_bytes = P.bytes;
     a.g_raw = g_raw; a.acts = acts; a.gbuf = gbuf; a.n_points = n_points;
     const int64_t ntiles = (n_points + 127) / 128;
     const int blocks = (int)(ntiles < 256 ? ntiles : 256);
-    switch (net->W / 32 + (net->use_viewdirs ? 0 : 100)) {
+    switch (net->W / 32 + (net->use_viewdirs ? 0 : 100) + (gmax ? 1000 : 0)) {
+        case 1008: hipLaunchKernelGGL((dgrad_x3_kernel<8, true, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1108: hipLaunchKernelGGL((dgrad_x3_kernel<8, false, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1004: hipLaunchKernelGGL((dgrad_x3_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 1104: hipLaunchKernelGGL((dgrad_x3_kernel<4, false, true>), dim3(blocks), dim3(256), 0, st, a); break;
         case 8: hipLaunchKernelGGL((dgrad_x3_kernel<8, true>), dim3(blocks), dim3(256), 0, st, a); break;
         case 108: hipLaunchKernelGGL((dgrad_x3_kernel<8, false>), dim3(blocks), dim3(256), 0, st, a); break;
         case 4: hipLaunchKernelGGL((dgrad_x3_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a); break;

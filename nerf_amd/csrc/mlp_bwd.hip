@@ -136,7 +136,7 @@ __device__ __forceinline__ void ln_bwd(f32x16 (&g)[NT], const TBuf &ta, const TB
 
 int launch_dgrad_x3(const nrf_net_t *net, const nrf_embed_t *emb, const NetPlan &plan, const float *packed,
                     const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf, int64_t n_points,
-                    hipStream_t st, int half_acts);      // mlp_bf16.hip
+                    hipStream_t st, int half_acts, const unsigned *gmax);      // mlp_bf16.hip
 
 struct DgradArgs {
     NetPlan plan;
@@ -407,9 +407,9 @@ __device__ __forceinline__ void wg_split(const f32x4 &p0, const f32x4 &p1, WgFra
 
 // the same from eight f16 values (TrainLayout::half_acts): an f16 is exactly hi + lo (11 significant bits)
 typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
-// (p BY VALUE, from a local copy of the LDS read: with `const u32x4 &p` bound to `*reinterpret_cast<const u32x4 *>(lds + ..)`
-// the compiler read ONE dword per fragment and used it for all four -- every weight gradient off by O(1), found with delta
-// patterns in a crafted workspace.)
+// (The elements go through scalar copies: `__builtin_bit_cast(wg_f16x2, p[w])` on a vector ELEMENT expression took element 0
+// for every w -- one dword of the fragment used for all four, every weight gradient off by O(1) with the right norm; found
+// with delta patterns in a crafted workspace.)
 __device__ __forceinline__ void wg_split_h(const u32x4 p, WgFrag &f) {
     const uint32_t pw[4] = {p[0], p[1], p[2], p[3]};
 #pragma unroll
@@ -513,7 +513,69 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
     }
 }
 
-template <bool X3, bool XH = false>
+// ---- training mode "w16": BOTH operands f16 (X as in XH; G pre-scaled by a power of two and saved as f16 by the dgrad
+// chain), so the contraction over points is ONE v_mfma_f32_32x32x16_f16 per tile pair on the fragments as they leave LDS --
+// no split, a third of the matrix work, half the bytes on both sides.  LDS per 8-point group: G tile x at x * 512, X tile y
+// at 8192 + y * 512 (1 KiB copies bring two adjacent tiles each).  Bias gradients = row sums of the G fragments (f32 adds).
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+template <int NA, int KA, class Req>
+__device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
+                                              int64_t nsteps, Req &&request) {
+    static_assert(kWgM == 2, "a step covers one 32x32x16 MFMA: two 8-point groups");
+    constexpr int NAr = NA ? NA : 1, KAr = KA ? KA : 1;
+    u32x4 A0[NAr], B0[KAr], A1[NAr], B1[KAr];
+    auto read_frags = [&](u32x4 (&A)[NAr], u32x4 (&B)[KAr], int stage) {
+        const char *base = lds + stage * kWgStage + (lane >> 5) * 16384 + (lane & 31) * 16;
+#pragma unroll
+        for (int x = 0; x < NA; ++x) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + (nt0 + x) * 512); A[x] = v; }
+#pragma unroll
+        for (int y = 0; y < KA; ++y) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + 8192 + (kt0 + y) * 512); B[y] = v; }
+    };
+    auto land = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int st_nxt = 1, st_req = 2;
+    auto body = [&](int64_t step, u32x4 (&A)[NAr], u32x4 (&B)[KAr], u32x4 (&An)[NAr], u32x4 (&Bn)[KAr]) {
+        land();
+        if (step + 2 < nsteps) request(step + 2, st_req);
+        if constexpr (NA > 0 && KA > 0) {
+            read_frags(An, Bn, st_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+                float r = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t e = A[x][w];   // a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0
+                    const wg_f32x2 v = __builtin_convertvector(__builtin_bit_cast(wg_f16x2, e), wg_f32x2);
+                    r += v[0] + v[1];
+                }
+                bs[x] += r;
+#pragma unroll
+                for (int y = 0; y < KA; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, A[x]),
+                                                                      __builtin_bit_cast(wg_f16x8, B[y]), acc[x][y], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
+        st_req = st_req == 2 ? 0 : st_req + 1;
+    };
+    if (nsteps > 0) {
+        request(0, 0);
+        request(1, 1);          // nsteps is even
+        land();
+        if constexpr (NA > 0 && KA > 0) read_frags(A0, B0, 0);
+    }
+    for (int64_t step = 0; step < nsteps; step += 2) {
+        body(step, A0, B0, A1, B1);
+        body(step + 1, A1, B1, A0, B0);
+    }
+}
+
+template <bool X3, bool XH = false, bool GH = false>
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
     // The argument block is indexed by a block-uniform value: read it where it lies, in the kernel-argument segment
@@ -579,7 +641,19 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
         for (int q = 0; q < 4; ++q) {
             const int i = wib + 4 * q;
             char *dst = lds + stage * kWgStage + i * 1024;
-            if (i < gn) {
+            if (GH && i < 4) {
+                // f16 G sections: as for X below, one 1 KiB copy = two adjacent 32-channel tiles of one 8-point group
+                if (2 * i < gn) {
+                    __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(gbuf) + tile * g_tile + a.g_sec, 0, a.Cg * 32 * 2, 0x00020000);
+#pragma unroll
+                    for (int mm = 0; mm < kWgM; ++mm)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
+                                                                 16, lane * 16,
+                                                                 (((m0 + mm) * a.Cg + 32 * (nsb * 8 + 2 * i)) * 8) * 2, 0, 0);
+                }
+            } else if (GH && i < 8) {
+            } else if (i < gn) {
 #pragma unroll
                 for (int mm = 0; mm < kWgM; ++mm)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
@@ -618,7 +692,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     // exact wait counts); waves of one workgroup may run different instances, all with the same barrier sequence.
     auto run = [&](auto na_c, auto ka_c) {
         constexpr int NA = decltype(na_c)::value, KA = decltype(ka_c)::value;
-        if constexpr (X3) wgrad_steps_x3<NA, KA, XH>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        if constexpr (GH) wgrad_steps_h<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        else if constexpr (X3) wgrad_steps_x3<NA, KA, XH>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
         else wgrad_steps<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
     };
     auto pick_k = [&](auto na_c) {
@@ -674,12 +749,16 @@ struct ReduceArgs {
 // Bandwidth-bound (nchunks x dW bytes): 4 lanes share one output quad, each summing a quarter of the chunks with
 // 8 float4 loads in flight, combined by shuffles in a FIXED order (bit-reproducible gradients).
 constexpr int kReduceBatch = 24;
-struct ReduceBatch { ReduceArgs e[kReduceBatch]; };
+struct ReduceBatch {
+    ReduceArgs e[kReduceBatch];
+    const unsigned *gmax;      // training mode "w16": the slabs hold gradients scaled by nrf_grad_scale(*gmax); else null
+};
 
 // All reductions of a backward pass in one launch: blockIdx.y picks the entry (every GEMM keeps its own slab region,
 // so nothing is reused between them); blocks beyond an entry's work leave at once.
 __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceBatch batch) {
     const ReduceArgs &a = batch.e[blockIdx.y];
+    const float unscale = batch.gmax ? nrf_grad_scale(*batch.gmax, true) : 1.0f;   // a power of two: exact
     const int kq = a.kn >> 2;                       // quads per row (kn is a multiple of 32)
     const int total_q = a.n_valid * kq;
     const int sub = threadIdx.x & 3;
@@ -713,7 +792,7 @@ __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceBatch ba
                     const int kk = k + i;
                     const int chan = (a.x_type == BLK_HIDDEN) ? (kk < a.k_valid ? kk : -1)
                                                               : blk_chan(a.x_type, a.x_param, a.x_ks, kk & 1, kk >> 1);
-                    if (chan >= 0) a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = v0[i];
+                    if (chan >= 0) a.dst_w[(int64_t)n * a.ld + a.ch_off + chan] = v0[i] * unscale;
                 }
             }
         } else if (a.dst_b) {   // bias rows: one lane group per row
@@ -725,7 +804,7 @@ __global__ void __launch_bounds__(256) reduce_unpack_kernel(const ReduceBatch ba
             }
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
-            if (sub == 0 && n < a.n_valid) a.dst_b[n] = v;
+            if (sub == 0 && n < a.n_valid) a.dst_b[n] = v * unscale;
         }
     }
 }
@@ -786,6 +865,17 @@ __global__ void __launch_bounds__(256) ln_param_reduce_kernel(const LnGradArgs a
     e.dst_b[c] = sb;
 }
 
+// Training mode "w16": bits of max |g_raw| over the pass (non-negative floats order as unsigned integers; *out zeroed by
+// the host side before the launch; the maximum does not depend on the order of the atomics)
+__global__ void __launch_bounds__(256) gmax_kernel(const float *__restrict__ g, int64_t n, unsigned *out) {
+    unsigned m = 0u;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(g[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
 struct Bwd {
     const nrf_net_t *net;
     const nrf_net_t *grads;
@@ -800,6 +890,7 @@ struct Bwd {
     int64_t slab_off = 0, slab_cap = 0;    // floats: every GEMM gets its own region of `slab`
     bool x3 = false;                       // wgrad on the bf16 matrix pipe (three bf16 MFMAs per product)
     bool xh = false;                       // x3 only: the activation sections hold f16 (TrainLayout::half_acts)
+    const unsigned *gmax = nullptr;        // "w16": gradient sections hold scaled f16 too; the weight GEMMs are one f16 MFMA
     ReduceBatch batch;
     int nbatch = 0, max_blocks = 1;
     WgradArgs wb{};
@@ -819,7 +910,8 @@ struct Bwd {
             wb.gbuf = gbuf; wb.acts = acts; wb.g_tile = tl.g_tile; wb.a_tile = tl.a_tile; wb.ntiles = ntiles;
             wb.chunk_tiles = chunk_tiles; wb.nchunks = nchunks;
             const unsigned blocks = (unsigned)npairs * (unsigned)nchunks;
-            if (x3 && xh) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(blocks), dim3(256), 0, st, wb);
+            if (gmax) hipLaunchKernelGGL((wgrad_kernel<true, true, true>), dim3(blocks), dim3(256), 0, st, wb);
+            else if (x3 && xh) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(blocks), dim3(256), 0, st, wb);
             else if (x3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, wb);
             else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, wb);
             nent = 0; npairs = 0;
@@ -827,6 +919,7 @@ struct Bwd {
             if (rc) return rc;
         }
         if (nbatch == 0) return NRF_OK;
+        batch.gmax = gmax;
         hipLaunchKernelGGL(reduce_unpack_kernel, dim3(max_blocks, nbatch), dim3(256), 0, st, batch);
         nbatch = 0; max_blocks = 1;
         return check_launch("nrf_query_bwd (slab reduction)");
@@ -900,6 +993,7 @@ extern "C" int64_t nrf_train_grads_floats(const nrf_net_t *net, int64_t n_points
     return ((n_points + 31) / 32) * tl.g_tile;
 }
 
+constexpr int kGmaxFloats = 64;     // the slab workspace ends with the scalar of gmax_kernel (training mode "w16")
 // LayerNorm nets: the partial sums of ln_param_grad_kernel live behind the weight-gradient slabs
 static int64_t ln_partial_floats(const nrf_net_t *net) {
     return net->use_layernorm ? (int64_t)kLnEntries * kLnChunks * 512 : 0;
@@ -913,7 +1007,7 @@ static int64_t slab_floats(const nrf_net_t *net, int64_t n_points, int max_chunk
     // (feature + alpha row) x cat[hidden, gamma(x), gamma(t)]
     const int64_t wp = (net->W + 31) / 32 * 32;      // the kernels' width: whole 32-channel tiles
     int64_t np = wp + 32, kp = wp + 2 * kKsX + 32;
-    return nchunks * (net->D + 3) * (np * kp + np) + ln_partial_floats(net);
+    return nchunks * (net->D + 3) * (np * kp + np) + ln_partial_floats(net) + kGmaxFloats;
 }
 
 extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points) { return slab_floats(net, n_points, 256); }
@@ -923,7 +1017,8 @@ extern "C" int64_t nrf_train_slab_floats(const nrf_net_t *net, int64_t n_points)
 static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time_ch, const float *packed,
                           const float *g_raw, const float *acts, float *gbuf, float *slab, int64_t n_points,
                           const nrf_net_t *grads, const float *pts, float *g_pts, void *stream, int max_chunks = 256,
-                          bool x3 = false, const void *packed_bwd_x3 = nullptr, bool straight = false, bool half_acts = false) {
+                          bool x3 = false, const void *packed_bwd_x3 = nullptr, bool straight = false, bool half_acts = false,
+                          bool half_grads = false) {
     NRF_REQUIRE(net && emb && grads, "nrf_query_bwd: null descriptor");
     if (n_points != 0) NRF_REQUIRE(net && emb && packed && g_raw && acts && gbuf && slab && grads, "nrf_query_bwd: null pointer");
     NRF_REQUIRE(n_points >= 0, "nrf_query_bwd: negative n_points");
@@ -948,7 +1043,17 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     if (half_acts && (!x3 || !packed_bwd_x3 || want_gx || straight || time_ch || pl.layernorm || emb->mode != 0))
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: the f16 activation workspace belongs to the static nets' bf16x3 "
                          "training kernels (parameter gradients only)");
-    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs, pl.layernorm, half_acts);
+    NRF_REQUIRE(!half_grads || half_acts, "nrf_query_bwd: the f16 gradient workspace goes with the f16 activation workspace");
+    d.plan = pl; d.tl = make_train_layout(nt, D, pl.use_viewdirs, pl.layernorm, half_acts, half_grads);
+    // "w16": the scalar the chain scales by lives in the last kGmaxFloats of the slab workspace
+    unsigned *gmax = nullptr;
+    if (half_grads) {
+        gmax = reinterpret_cast<unsigned *>(slab + slab_floats(net, n_points, max_chunks) - kGmaxFloats);
+        hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned), st);
+        if (me != hipSuccess) return nrf::fail(NRF_ERR_LAUNCH, "nrf_query_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
+        const int64_t nraw = n_points * pl.output_ch;
+        hipLaunchKernelGGL(gmax_kernel, dim3((unsigned)std::min<int64_t>((nraw + 255) / 256, 1024)), dim3(256), 0, st, g_raw, nraw, gmax);
+    }
     d.packed = packed; d.g_raw = g_raw; d.acts = acts; d.gbuf = gbuf; d.n_points = n_points;
     const int64_t ntiles = (n_points + 31) / 32;
     int blocks = (int)((ntiles + 3) / 4);
@@ -957,7 +1062,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
     // the chain on the bf16 matrix pipe, where a kernel exists: static nets, and the deformation net (its chain ends at its
     // own parameters: nothing downstream amplifies the 1e-5 of this arithmetic, unlike the canonical net's d/dx)
     if (x3 && packed_bwd_x3 && !want_gx && !straight)
-        x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st, half_acts);
+        x3rc = launch_dgrad_x3(net, emb, pl, packed, packed_bwd_x3, g_raw, acts, gbuf, n_points, st, half_acts, gmax);
     if (half_acts && x3rc != NRF_OK)
         return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd_bf16x3_a16: this shape has no bf16x3 kernels (W = 128, 256; D >= 2)");
     if (x3rc != NRF_OK && x3rc != NRF_ERR_UNSUPPORTED) return x3rc;
@@ -1004,12 +1109,12 @@ dgrad_done:
 
     Bwd B{};
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
-    B.ntiles = ntiles; B.st = st; B.x3 = x3; B.xh = half_acts;
+    B.ntiles = ntiles; B.st = st; B.x3 = x3; B.xh = half_acts; B.gmax = gmax;
     B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, max_chunks);
-    B.slab_cap = slab_floats(net, n_points, max_chunks) - ln_partial_floats(net);
+    B.slab_cap = slab_floats(net, n_points, max_chunks) - ln_partial_floats(net) - kGmaxFloats;
     if (pl.layernorm) {   // the affine parameters' gradients: independent of the weight-gradient GEMMs below
         LnGradArgs la{};
-        la.gbuf = gbuf; la.acts = acts; la.partial = slab + B.slab_cap;
+        la.gbuf = gbuf; la.acts = acts; la.partial = slab + B.slab_cap;     // (then the kGmaxFloats tail)
         la.g_tile = d.tl.g_tile; la.a_tile = d.tl.a_tile; la.ntiles = ntiles;
         la.nchunks = (int)std::min<int64_t>(ntiles, kLnChunks);
         la.chunk_tiles = (int)((ntiles + la.nchunks - 1) / la.nchunks);
@@ -1036,7 +1141,7 @@ dgrad_done:
     const Bwd::XPart Xin{tl.a_xin, 2 * kKsX, xk, pl.x_type, pl.x_param, kKsX, 0, 0};
     for (int l = 0; l < D; ++l) {
         NRF_REQUIRE(grads->pts_w[l] && grads->pts_b[l], "nrf_query_bwd: grads->pts_w/pts_b[%d] is null", l);
-        const int64_t gsec = tl.g_trunk + (int64_t)l * 32 * Wp;
+        const int64_t gsec = tl.g_trunk + (int64_t)l * (tl.half_grads ? 16 : 32) * Wp;
         bool skip = l > 0 && ((net->skips_mask >> (l - 1)) & 1);
         const int skip_ch = ic + (straight ? time_ch : 0);     // a straightforward net's skip reads cat[gamma(x), gamma(t), h]
         int ld = l == 0 ? ic + time_ch : (W + (skip ? skip_ch : 0));
@@ -1117,6 +1222,19 @@ extern "C" int nrf_query_bwd_bf16x3_a16(const nrf_net_t *net, const nrf_embed_t 
     NRF_REQUIRE(packed_bwd_x3, "nrf_query_bwd_bf16x3_a16: packed_bwd_x3 is null");
     return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, nullptr, nullptr, stream, 256, true,
                           packed_bwd_x3, false, true);
+}
+
+/* Training mode "w16": nrf_query_bwd_bf16x3_a16 with the gradient blocks saved as f16 as well -- the activation-gradient
+ * chain (bf16x3, unchanged arithmetic) runs on gradients scaled by the power of two that brings the pass's largest
+ * |g_raw| into [2^10, 2^11) and saves its blocks as f16 (saturating), the weight-gradient GEMMs are ONE f16 MFMA per tile pair
+ * on the two f16 workspaces, and the slab reduction undoes the scale.  What mixed-precision training calls loss scaling;
+ * weight AND bias gradients then carry a 2^-12 rounding of both operands. */
+extern "C" int nrf_query_bwd_bf16x3_w16(const nrf_net_t *net, const nrf_embed_t *emb, const float *packed,
+                                        const void *packed_bwd_x3, const float *g_raw, const float *acts, float *gbuf,
+                                        float *slab, int64_t n_points, const nrf_net_t *grads, void *stream) {
+    NRF_REQUIRE(packed_bwd_x3, "nrf_query_bwd_bf16x3_w16: packed_bwd_x3 is null");
+    return query_bwd_impl(net, emb, 0, packed, g_raw, acts, gbuf, slab, n_points, grads, nullptr, nullptr, stream, 256, true,
+                          packed_bwd_x3, false, true, true);
 }
 
 extern "C" int nrf_dnerf_time_bwd_bf16x3(const nrf_net_t *time_net, const nrf_embed_t *emb, const float *packed_time,

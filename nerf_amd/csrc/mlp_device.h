@@ -672,6 +672,23 @@ __device__ __forceinline__ void axpy_head(f32x16 (&g)[NT], const WBuf &wb, uint3
 
 __device__ __forceinline__ float pow2i(int f) { return __int_as_float((127 + f) << 23); }
 
+// Training mode "w16": the power of two that brings the step's largest |d(loss)/d(raw)| (its bits: gmax_kernel) into
+// [2^10, 2^11) -- the scale of the f16 gradient workspace: gradients of inner layers are mostly SMALLER than d/d(raw) (sums of
+// products with weights ~ 1/16), so the window is placed high: 2^5 of headroom to f16's 65504 (beyond it the store
+// saturates) and full 11-bit precision down to 2^-24 of the largest value.  (Measured on the test nets: the window's place
+// -- maximum at 1 or at 2^10 -- does not move the error, which is the 2^-12 rounding of the two operands.)  inv = true: the
+// factor that takes a weight gradient back.
+constexpr int kGradWindowLog2 = 10;
+__host__ __device__ __forceinline__ int nrf_grad_exponent(unsigned maxbits) {
+    int e = (int)((maxbits >> 23) & 0xffu) - 127 - kGradWindowLog2;
+    if (maxbits == 0u) e = 0;
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__device__ __forceinline__ float nrf_grad_scale(unsigned maxbits, bool inv = false) {
+    const int e = nrf_grad_exponent(maxbits);
+    return pow2i(inv ? e : -e);
+}
+
 // sin and cos of one encoder argument, |a| <= kSincosMax (every frequency of a scene-sized coordinate: x * 2^9 with
 // |x| <= 32; callers test their largest argument and use the library's sincosf beyond it).  Two-FMA Cody-Waite
 // reduction by pi/2 (n * c is exact inside the FMA), degree-7/8 minimax polynomials on [-pi/4, pi/4]: max abs error

@@ -121,6 +121,8 @@ struct TrainLayout {
                                      // (D sections of W) and of the view layer: what the LayerNorm backward differentiates
     int64_t a_rstd;                  // LayerNorm nets only: D + 1 slots of 32 floats: 1 / sqrt(var + eps) of each point
     int64_t a_tile;                  // floats per tile
+    int32_t half_grads, pad2_;       // 1: the gradient sections g_trunk / g_feat / g_hv / g_head hold f16 values (pre-scaled by a
+                                     // power of two, training mode "w16"): 16 * C floats per section of C channels
     // gradients w.r.t. pre-activations
     int64_t g_trunk;                 // D sections of W
     int64_t g_feat;                  // W + 32: the extra tile's row 0 is d/d(alpha)
@@ -132,7 +134,8 @@ struct TrainLayout {
     int64_t g_tile;
 };
 
-NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs, int layernorm = 0, int half_acts = 0) {
+NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs, int layernorm = 0, int half_acts = 0,
+                                            int half_grads = 0) {
     TrainLayout t{};
     t.nt = nt; t.n_trunk = D; t.use_viewdirs = use_viewdirs;
     const int W = 32 * nt;
@@ -154,11 +157,13 @@ NRF_HD inline TrainLayout make_train_layout(int nt, int D, int use_viewdirs, int
         t.a_rstd = c; c += (int64_t)32 * (D + 1);
     }
     t.a_tile = c;
+    t.half_grads = half_grads;
+    const int gp = half_grads ? 16 : 32;
     c = 0;
-    t.g_trunk = c; c += (int64_t)32 * W * D;
-    t.g_feat = c; c += 32 * (W + 32);
-    t.g_hv = c; c += 32 * Wv;
-    t.g_head = c; c += 32 * 32;
+    t.g_trunk = c; c += (int64_t)gp * W * D;
+    t.g_feat = c; c += gp * (W + 32);
+    t.g_hv = c; c += gp * Wv;
+    t.g_head = c; c += gp * 32;
     t.g_xin = c; c += 32 * 64;
     t.g_ln = t.g_ln_v = -1;
     if (layernorm) {

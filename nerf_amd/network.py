@@ -30,14 +30,18 @@ class _QueryFunction(torch.autograd.Function):
             packed.refresh()                     # the backward reads this f32 copy (W^T blocks of the dgrad chain)
             fwd = packed
             x3_shape = key[0] == 0 and module.W in (128, 256)
-            if module.train_precision in ("bf16x3", "bf16x3_a16") and x3_shape:
+            if module.train_precision in ("bf16x3", "bf16x3_a16", "bf16x3_w16") and x3_shape:
                 fwd = module._packed(key + ("bf16x3",))      # the forward alone runs on the bf16 matrix pipe
-            elif module.train_precision not in ("fp32", "bf16x3", "bf16x3_a16"):
-                raise ValueError(f"train_precision must be 'fp32', 'bf16x3' or 'bf16x3_a16', not {module.train_precision!r}")
+            elif module.train_precision not in ("fp32", "bf16x3", "bf16x3_a16", "bf16x3_w16"):
+                raise ValueError("train_precision must be 'fp32', 'bf16x3', 'bf16x3_a16' or 'bf16x3_w16', not "
+                                 f"{module.train_precision!r}")
             # "bf16x3_a16": the activations are saved as f16 (half the workspace bytes written and read back); needs the
             # bf16x3 chain kernels (D >= 2) and parameter gradients only, otherwise plain bf16x3
-            a16 = (fwd is not packed and module.train_precision == "bf16x3_a16" and module.D >= 2
+            # "bf16x3_w16": the gradient blocks as (scaled) f16 too, weight-gradient GEMMs as one f16 MFMA per tile pair
+            a16 = (fwd is not packed and module.train_precision in ("bf16x3_a16", "bf16x3_w16") and module.D >= 2
                    and not pts.requires_grad)
+            if a16 and module.train_precision == "bf16x3_w16":
+                a16 = "w16"
             raw, acts = fwd.query_train(pts, viewdirs, pts_per_ray, a16=True) if a16 else fwd.query_train(pts, viewdirs, pts_per_ray)
             ctx.a16 = a16
             ctx.module, ctx.key, ctx.n_points = module, key, pts.shape[0]
@@ -98,7 +102,8 @@ class NeRF(nn.Module):
         # training forward and weight-gradient GEMMs as three bf16 MFMAs per product on hi/residual operands (f32-grade:
         # raw within 1e-5 of its scale, gradients within the same 2e-3 of the reference's autograd); "bf16x3_a16" = the
         # same with the saved activations in f16 (half the bytes of the step's largest workspace: weight gradients carry
-        # a 2^-12 rounding of the activations, ~2e-4 of their norm)
+        # a 2^-12 rounding of the activations, ~2e-4 of their norm); "bf16x3_w16" = that plus the gradient blocks saved as
+        # f16 under a per-pass power-of-two scale, the weight-gradient GEMMs then run as single f16 MFMAs
         self.train_precision = "fp32"
 
     # ------------------------------------------------------------------ packed weights

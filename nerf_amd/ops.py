@@ -289,7 +289,8 @@ class PackedNet:
     def query_bwd(self, g_raw, n_points, acts, pts=None, x3=False, a16=False):
         """-> dict name -> gradient tensor (same shapes as the parameters); with `pts` (the query points of the
         forward) -> (that dict, d(loss)/d(pts) [P,3]).  x3: the weight-gradient GEMMs on the bf16x3 arithmetic.
-        a16: `acts` holds f16 activations (PackedNetBf16x3.query_train(a16=True)); needs x3=True, parameters only."""
+        a16: `acts` holds f16 activations (PackedNetBf16x3.query_train(a16=True)); needs x3=True, parameters only.
+        a16 = "w16": the gradient blocks are saved as (scaled) f16 too and the weight-gradient GEMMs run on the f16 MFMA."""
         g_raw = _f32(g_raw, "g_raw")
         dev = g_raw.device
         lib = _lib.lib()
@@ -325,9 +326,9 @@ class PackedNet:
             if not x3 or x3 == "wgrad" or pts is not None or self.bwd_x3_stream() is None:
                 raise RuntimeError("nerf_amd: the f16 activation workspace belongs to the bf16x3 training kernels of static "
                                    "nets (W = 128, 256; parameter gradients only)")
-            check(lib.nrf_query_bwd_bf16x3_a16(C.byref(self.net), C.byref(self.emb), _ptr(self.packed),
-                                               _ptr(self.bwd_x3_stream()), _ptr(g_raw), _ptr(acts), _ptr(gbuf), _ptr(slab),
-                                               n_points, C.byref(gn), _stream()), "nrf_query_bwd_bf16x3_a16")
+            fn = "nrf_query_bwd_bf16x3_w16" if a16 == "w16" else "nrf_query_bwd_bf16x3_a16"
+            check(getattr(lib, fn)(C.byref(self.net), C.byref(self.emb), _ptr(self.packed), _ptr(self.bwd_x3_stream()),
+                                   _ptr(g_raw), _ptr(acts), _ptr(gbuf), _ptr(slab), n_points, C.byref(gn), _stream()), fn)
             return grads
         if x3:
             g_pts = None

@@ -51,7 +51,7 @@ def test_version_and_size_queries():
     per_pt = l.nrf_train_acts_floats(C.byref(n), pts) / pts
     assert per_pt == 64 + 32 + 24 + 8 * 256 + 256 + 128 + 8 * 9      # k-space inputs + trunk + feature + view layer
     assert l.nrf_train_grads_floats(C.byref(n), pts) / pts == 8 * 256 + 288 + 128 + 32 + 64
-    assert l.nrf_train_slab_floats(C.byref(n), pts) == 256 * 11 * (288 * 352 + 288)   # every GEMM its own slab region
+    assert l.nrf_train_slab_floats(C.byref(n), pts) == 256 * 11 * (288 * 352 + 288) + 64   # every GEMM its own slab region (+ the w16 scalar)
     # ragged point counts round up to whole 32-point tiles
     assert l.nrf_train_acts_floats(C.byref(n), 33) == 2 * 32 * per_pt
 

@@ -36,7 +36,8 @@ def make_nets(train_precision="fp32"):
 # the training kernels in the reference's f32 arithmetic, and on the bf16x3 arithmetic (three bf16 MFMAs per product on
 # hi/residual operands): both against the SAME reference autograd goldens and the same bars
 # "bf16x3_a16": bf16x3 with the saved activations in f16 (half the bytes of the step's largest workspace)
-TRAIN_PRECISIONS = ["fp32", "bf16x3", "bf16x3_a16"]
+# "bf16x3_w16": that plus the gradient blocks as scaled f16, weight-gradient GEMMs as single f16 MFMAs
+TRAIN_PRECISIONS = ["fp32", "bf16x3", "bf16x3_a16", "bf16x3_w16"]
 
 
 def check_grads(net, gold, tag, tol):
@@ -285,6 +286,26 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
         if k.endswith("bias"):       # bias gradients are row sums of G alone: untouched by the activations' format
             assert e <= 5e-5, (k, e)
     print(f"a16 {cfg}: weight gradients within {worst:.1e} of their scale of the f32-workspace bf16x3 backward")
+    # "w16": the gradient blocks saved as f16 too (scaled by the power of two that brings max |g_raw| into [2^10, 2^11)), one
+    # f16 MFMA per tile pair, the reduction undoes the scale -- also when the incoming gradient is tiny or huge.  Both
+    # operands of every product carry a 2^-12 rounding: <= 1.5e-3 of a gradient's norm (measured: 2-4e-4 for the
+    # layers' matrices, 9.6e-4 for alpha_linear's single row, whose sum over the points cancels the most), <= 3e-3 of its largest
+    # element on the worst of 65 536 elements (measured 1.7e-3); against the reference's autograd every golden holds 2e-3
+    for mag in (1.0, 3e-7, 5e4):
+        grads_ref = f32.query_bwd(g_raw * mag, P, acts_b, x3=True)
+        grads_w = f32.query_bwd(g_raw * mag, P, acts_c, x3=True, a16="w16")
+        worst, worst_f = 0.0, 0.0
+        for k in grads_ref:
+            sc = max(float(grads_ref[k].abs().max()), 1e-30)
+            e = float((grads_ref[k] - grads_w[k]).abs().max()) / sc
+            ef = float((grads_ref[k] - grads_w[k]).double().norm() / max(float(grads_ref[k].double().norm()), 1e-30))
+            worst, worst_f = max(worst, e), max(worst_f, ef)
+            if grads_ref[k].numel() >= 64:
+                assert e <= 3e-3 and ef <= 1.5e-3, (mag, k, e, ef)
+            else:       # a handful of sums of 2 560 signed terms (alpha_linear.bias is ONE): relative to a sum that cancels
+                assert e <= 1e-2, (mag, k, e)
+        print(f"w16 {cfg} (|g_raw| x {mag:g}): gradients within {worst_f:.1e} of their norm ({worst:.1e} of their largest "
+              "element) of the f32-workspace bf16x3 backward")
 
 
 @pytest.mark.parametrize("train_precision", TRAIN_PRECISIONS)
