@@ -514,70 +514,97 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
 }
 
 // ---- training mode "w16": BOTH operands f16 (X as in XH; G pre-scaled by a power of two and saved as f16 by the dgrad
-// chain), so the contraction over points is ONE v_mfma_f32_32x32x16_f16 per tile pair on the fragments as they leave LDS --
-// no split, a third of the matrix work, half the bytes on both sides.  LDS per 8-point group: G tile x at x * 512, X tile y
-// at 8192 + y * 512 (1 KiB copies bring two adjacent tiles each).  Bias gradients = row sums of the G fragments (f32 adds).
+// chain), so the contraction over points is ONE v_mfma_f32_32x32x16_f16 per tile pair and 16 points on the fragments as they
+// leave LDS -- no split, a third of the matrix work, half the bytes on both sides.  With so little arithmetic per byte the
+// loop is bound by how many copies are in flight, so it is laid out for that (the first version kept the x3 loop's shape --
+// 16 points a step, copies one step ahead, vmcnt(0) -- and ran at 3.6 TB/s with the matrix pipe 19 % busy):
+//   * a step is a whole 32-point tile (four 8-point groups, two MFMAs per tile pair): half the barriers;
+//   * FOUR LDS stages of 32 KiB (per group: G tiles at x * 512, X tiles at 4096 + y * 512; a 1 KiB copy brings two adjacent
+//     tiles), copies FOUR steps ahead (the running step's operands sit in registers, so its stage is free), and the wait
+//     before the barrier is COUNTED: vector-memory operations retire in order, so vmcnt(2 * nd) -- nd = this wave's copies
+//     per step -- returns when the step about to be read has landed and leaves the two younger steps in flight: 32 to 48 KiB
+//     per CU, 8 to 12 MiB over the chip.
+// Bias gradients = row sums of the G fragments (f32 adds).
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kHStage = 32768, kHStages = 4, kHGroup = 8192;
 template <int NA, int KA, class Req>
 __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
-                                              int64_t nsteps, Req &&request) {
-    static_assert(kWgM == 2, "a step covers one 32x32x16 MFMA: two 8-point groups");
+                                              int64_t nsteps, int nd, Req &&request) {
     constexpr int NAr = NA ? NA : 1, KAr = KA ? KA : 1;
-    u32x4 A0[NAr], B0[KAr], A1[NAr], B1[KAr];
-    auto read_frags = [&](u32x4 (&A)[NAr], u32x4 (&B)[KAr], int stage) {
-        const char *base = lds + stage * kWgStage + (lane >> 5) * 16384 + (lane & 31) * 16;
+    u32x4 A0[2][NAr], B0[2][KAr], A1[2][NAr], B1[2][KAr];
+    auto read_frags = [&](u32x4 (&A)[2][NAr], u32x4 (&B)[2][KAr], int stage) {
 #pragma unroll
-        for (int x = 0; x < NA; ++x) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + (nt0 + x) * 512); A[x] = v; }
+        for (int kb = 0; kb < 2; ++kb) {        // k-block kb of the tile's 32 points: groups 2 kb (lanes 0-31) and 2 kb + 1
+            const char *base = lds + stage * kHStage + (2 * kb + (lane >> 5)) * kHGroup + (lane & 31) * 16;
 #pragma unroll
-        for (int y = 0; y < KA; ++y) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + 8192 + (kt0 + y) * 512); B[y] = v; }
+            for (int x = 0; x < NA; ++x) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + (nt0 + x) * 512); A[kb][x] = v; }
+#pragma unroll
+            for (int y = 0; y < KA; ++y) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + 4096 + (kt0 + y) * 512); B[kb][y] = v; }
+        }
     };
-    auto land = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // own copies of the step about to be read have landed (`younger` later steps may stay in flight); after the barrier
+    // everyone's have
+    auto land = [&](int younger) {
+        switch (younger * nd) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;       // 3 * 8
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    int st_nxt = 1, st_req = 2;
-    auto body = [&](int64_t step, u32x4 (&A)[NAr], u32x4 (&B)[KAr], u32x4 (&An)[NAr], u32x4 (&Bn)[KAr]) {
-        land();
-        if (step + 2 < nsteps) request(step + 2, st_req);
+    int st_nxt = 1, st_req = 0;
+    auto body = [&](int64_t step, u32x4 (&A)[2][NAr], u32x4 (&B)[2][KAr], u32x4 (&An)[2][NAr], u32x4 (&Bn)[2][KAr]) {
+        // requests issued so far: steps <= step + 3; the one read now is step + 1
+        const int64_t last = nsteps - 1 < step + 3 ? nsteps - 1 : step + 3;
+        land(last > step + 1 ? (int)(last - (step + 1)) : 0);
+        // stage (step + 4) % 4 is this step's own: its fragments went to registers a step ago, and every wave is past that read
+        if (step + 4 < nsteps) request(step + 4, st_req);
         if constexpr (NA > 0 && KA > 0) {
-            read_frags(An, Bn, st_nxt);
+            read_frags(An, Bn, st_nxt);     // past the last step this re-reads a stale stage: unused
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int x = 0; x < NA; ++x) {
-                float r = 0.0f;
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t e = A[x][w];   // a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0
-                    const wg_f32x2 v = __builtin_convertvector(__builtin_bit_cast(wg_f16x2, e), wg_f32x2);
-                    r += v[0] + v[1];
+                for (int x = 0; x < NA; ++x) {
+                    float r = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t e = A[kb][x][w];   // a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0
+                        const wg_f32x2 v = __builtin_convertvector(__builtin_bit_cast(wg_f16x2, e), wg_f32x2);
+                        r += v[0] + v[1];
+                    }
+                    bs[x] += r;
+#pragma unroll
+                    for (int y = 0; y < KA; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, A[kb][x]),
+                                                                          __builtin_bit_cast(wg_f16x8, B[kb][y]), acc[x][y], 0, 0, 0);
                 }
-                bs[x] += r;
-#pragma unroll
-                for (int y = 0; y < KA; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, A[x]),
-                                                                      __builtin_bit_cast(wg_f16x8, B[y]), acc[x][y], 0, 0, 0);
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        st_nxt = st_nxt == 2 ? 0 : st_nxt + 1;
-        st_req = st_req == 2 ? 0 : st_req + 1;
+        st_nxt = (st_nxt + 1) & 3;
+        st_req = (st_req + 1) & 3;
     };
     if (nsteps > 0) {
         request(0, 0);
-        request(1, 1);          // nsteps is even
-        land();
+        if (nsteps > 1) request(1, 1);
+        if (nsteps > 2) request(2, 2);
+        if (nsteps > 3) request(3, 3);
+        land(nsteps > 3 ? 3 : (int)(nsteps - 1));
         if constexpr (NA > 0 && KA > 0) read_frags(A0, B0, 0);
     }
     for (int64_t step = 0; step < nsteps; step += 2) {
         body(step, A0, B0, A1, B1);
-        body(step + 1, A1, B1, A0, B0);
+        if (step + 1 < nsteps) body(step + 1, A1, B1, A0, B0);
     }
 }
 
 template <bool X3, bool XH = false, bool GH = false>
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
-    __shared__ __attribute__((aligned(1024))) char lds[3 * kWgStage];
+    __shared__ __attribute__((aligned(1024))) char lds[GH ? kHStages * kHStage : 3 * kWgStage];
     // The argument block is indexed by a block-uniform value: read it where it lies, in the kernel-argument segment
     // (constant address space -> scalar loads).  Indexing the by-value parameter made the compiler copy all 1.3 KB of it
     // to per-lane scratch memory at the top of every workgroup.
@@ -628,32 +655,48 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
 
     const int64_t t0 = (int64_t)chunk * b.chunk_tiles;
     const int64_t t1 = min(b.ntiles, t0 + b.chunk_tiles);
-    constexpr int kSpt = 4 / kWgM;                 // steps per 32-point tile
-    const int64_t nsteps = (t1 - t0) * kSpt;       // one step = kWgM groups of 8 points of one tile
+    constexpr int kSpt = GH ? 1 : 4 / kWgM;        // steps per 32-point tile
+    const int64_t nsteps = (t1 - t0) * kSpt;       // one step = kWgM groups of 8 points of one tile (GH: the whole tile)
+    // GH: wave w copies G tile pair w and X tile pair w of all four point groups: 4 copies each
+    const bool h_g = 2 * wib < gn, h_x = 2 * wib < xn;
+    const int nd = GH ? 4 * ((int)h_g + (int)h_x) : 0;
 
     // copy this wave's share of step `step`'s pieces into `stage`: piece i (G pieces first, then X) by wave i & 3
     auto request = [&](int64_t step, int stage) {
         const int64_t tile = t0 + step / kSpt;
         const int m0 = (int)(step % kSpt) * kWgM;
+        if constexpr (GH) {
+            // both sides f16: a 1 KiB copy = two adjacent 32-channel tiles of one 8-point group (64 channels x 16 bytes;
+            // lanes beyond the section read zeros or a tile no fragment uses)
+            char *dst = lds + stage * kHStage + wib * 1024;
+            if (h_g) {
+                __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(gbuf) + tile * g_tile + a.g_sec, 0, a.Cg * 32 * 2, 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(dst + m * kHGroup), 16,
+                                                             lane * 16, ((m * a.Cg + 32 * (nsb * 8 + 2 * wib)) * 8) * 2, 0, 0);
+            }
+            if (h_x) {
+                const int kt = ksb * 8 + 2 * wib;
+                const int sec = kt >= a.k_tiles0;
+                const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
+                __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(acts) + tile * a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 2, 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dst + 4096 + m * kHGroup),
+                                                             16, lane * 16, ((m * a.Ca[sec] + c0) * 8) * 2, 0, 0);
+            }
+            return;
+        }
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(gbuf) + tile * g_tile + a.g_sec, 0, a.Cg * 32 * 4, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = wib + 4 * q;
             char *dst = lds + stage * kWgStage + i * 1024;
-            if (GH && i < 4) {
-                // f16 G sections: as for X below, one 1 KiB copy = two adjacent 32-channel tiles of one 8-point group
-                if (2 * i < gn) {
-                    __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<float *>(gbuf) + tile * g_tile + a.g_sec, 0, a.Cg * 32 * 2, 0x00020000);
-#pragma unroll
-                    for (int mm = 0; mm < kWgM; ++mm)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
-                                                                 16, lane * 16,
-                                                                 (((m0 + mm) * a.Cg + 32 * (nsb * 8 + 2 * i)) * 8) * 2, 0, 0);
-                }
-            } else if (GH && i < 8) {
-            } else if (i < gn) {
+            if (i < gn) {
 #pragma unroll
                 for (int mm = 0; mm < kWgM; ++mm)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(dst + mm * 16384),
@@ -692,7 +735,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     // exact wait counts); waves of one workgroup may run different instances, all with the same barrier sequence.
     auto run = [&](auto na_c, auto ka_c) {
         constexpr int NA = decltype(na_c)::value, KA = decltype(ka_c)::value;
-        if constexpr (GH) wgrad_steps_h<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        if constexpr (GH) wgrad_steps_h<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, nd, request);
         else if constexpr (X3) wgrad_steps_x3<NA, KA, XH>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
         else wgrad_steps<NA, KA>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
     };
@@ -705,7 +748,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
         }
     };
     if (!active) {
-        wgrad_steps<0, 0>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
+        if constexpr (GH) wgrad_steps_h<0, 0>(acc, bs, lds, lane, nt0, kt0, nsteps, nd, request);
+        else wgrad_steps<0, 0>(acc, bs, lds, lane, nt0, kt0, nsteps, request);
     } else {
         switch (na) {
             case 1: pick_k(std::integral_constant<int, 1>{}); break;
@@ -868,12 +912,36 @@ __global__ void __launch_bounds__(256) ln_param_reduce_kernel(const LnGradArgs a
 // Training mode "w16": bits of max |g_raw| over the pass (non-negative floats order as unsigned integers; *out zeroed by
 // the host side before the launch; the maximum does not depend on the order of the atomics)
 __global__ void __launch_bounds__(256) gmax_kernel(const float *__restrict__ g, int64_t n, unsigned *out) {
+    __shared__ unsigned part[4];
     unsigned m = 0u;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    // float4 loads, four in flight per lane, where g is 16-byte aligned; scalars for the rest
+    const int64_t nq = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? n >> 2 : 0, stride = (int64_t)gridDim.x * blockDim.x;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nq; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = g4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m = max(m, __float_as_uint(v[u][c]) & 0x7fffffffu);
+    }
+    for (; i < nq; i += stride) {
+        const f32x4 v = g4[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m = max(m, __float_as_uint(v[c]) & 0x7fffffffu);
+    }
+    for (i = 4 * nq + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
         m = max(m, __float_as_uint(g[i]) & 0x7fffffffu);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m != 0u) atomicMax(out, m);     // one per block
+    }
 }
 
 struct Bwd {
@@ -1052,7 +1120,7 @@ static int query_bwd_impl(const nrf_net_t *net, const nrf_embed_t *emb, int time
         hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned), st);
         if (me != hipSuccess) return nrf::fail(NRF_ERR_LAUNCH, "nrf_query_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
         const int64_t nraw = n_points * pl.output_ch;
-        hipLaunchKernelGGL(gmax_kernel, dim3((unsigned)std::min<int64_t>((nraw + 255) / 256, 1024)), dim3(256), 0, st, g_raw, nraw, gmax);
+        hipLaunchKernelGGL(gmax_kernel, dim3((unsigned)std::min<int64_t>((nraw + 1023) / 1024, 512)), dim3(256), 0, st, g_raw, nraw, gmax);
     }
     d.packed = packed; d.g_raw = g_raw; d.acts = acts; d.gbuf = gbuf; d.n_points = n_points;
     const int64_t ntiles = (n_points + 31) / 32;

@@ -21,7 +21,7 @@ def mfma_util(src, dst, rnd):
     util = {"_note": "one rocprofv3 --pmc pass per workload (7 SQ counters + GRBM_GUI_ACTIVE), scripts/profile_gpu.sh sq_all; "
                      "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration; "
                      "profiled passes run slower than un-profiled ones (counter collection serialises launches)"}
-    for w in ("render", "render_bf16", "render_bf16x3", "train", "train_bf16x3", "train_bf16x3_a16", "dnerf", "dnerf_bf16"):
+    for w in ("render", "render_bf16", "render_bf16x3", "train", "train_bf16x3", "train_bf16x3_a16", "train_bf16x3_w16", "dnerf", "dnerf_bf16"):
         p = os.path.join(src, f"pmc_{w}_sq.summary.json")
         if not os.path.exists(p):
             continue
@@ -54,14 +54,14 @@ def main(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for w in ("render", "train", "train_bf16x3", "train_bf16x3_a16", "dnerf", "dnerf_bf16", "dnerf_bf16x3", "render_bf16", "render_bf16x3",
+    for w in ("render", "train", "train_bf16x3", "train_bf16x3_a16", "train_bf16x3_w16", "dnerf", "dnerf_bf16", "dnerf_bf16x3", "render_bf16", "render_bf16x3",
               "dnerf_straight", "fern"):
         p = os.path.join(src, f"stats_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{rnd}_{w}_kernel_stats.csv"))
     traffic = {"_note": "per-launch means from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
                         "`bench.py --steps 1` (scripts/profile_gpu.sh); KiB * 1024; fetch_corrected = 2 * fetch_raw"}
-    for w in ("render", "train", "train_bf16x3", "train_bf16x3_a16", "dnerf", "render_bf16", "render_bf16x3"):
+    for w in ("render", "train", "train_bf16x3", "train_bf16x3_a16", "train_bf16x3_w16", "dnerf", "render_bf16", "render_bf16x3"):
         per = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             p = os.path.join(src, f"pmc_{w}_{c}.summary.json")
@@ -84,7 +84,7 @@ def main(tag, rnd):
                 e["hbm_bytes"] = e["fetch_bytes_corrected"] + e["write_bytes"]
         if per:
             # steps executed by the profiled command (scripts/profile_gpu.sh: render 0+1, train 1+1, dnerf 0+1)
-            per["_steps_profiled"] = {"render": 1, "train": 2, "train_bf16x3": 2, "train_bf16x3_a16": 2, "dnerf": 1, "render_bf16": 1, "render_bf16x3": 1}[w]
+            per["_steps_profiled"] = {"render": 1, "train": 2, "train_bf16x3": 2, "train_bf16x3_a16": 2, "train_bf16x3_w16": 2, "dnerf": 1, "render_bf16": 1, "render_bf16x3": 1}[w]
             traffic[w] = per
     mfma_util(src, dst, rnd)
     if len(traffic) == 1:        # an SQ-only run: leave the traffic file of the round alone

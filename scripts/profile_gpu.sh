@@ -24,13 +24,14 @@ for what in "$@"; do
         timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_train_bf16x3_$c" -o train_bf16x3 -- python3 $TX3 --steps 1 --warmup 1 > "$OUT/pmc_train_bf16x3_$c.log" 2>&1
       done
       timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_train_bf16x3_sq" -o train_bf16x3 -- python3 $TX3 --steps 2 --warmup 1 > "$OUT/pmc_train_bf16x3_sq.log" 2>&1 ;;
-    train_a16)   # bf16x3 training with the saved activations in f16: kernel stats, HBM traffic, SQ pass
-      TA="$ROOT/bench.py --workload train --train-precision bf16x3_a16"
-      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train_bf16x3_a16" -o train_bf16x3_a16 -- python3 $TA --steps 5 --warmup 2 > "$OUT/train_bf16x3_a16_stats.log" 2>&1
+    train_a16|train_w16)   # bf16x3 training with f16 workspaces (a16: activations; w16: gradient blocks too): stats, HBM traffic, SQ
+      M=${what#train_}
+      TA="$ROOT/bench.py --workload train --train-precision bf16x3_$M"
+      timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train_bf16x3_$M" -o train_bf16x3_$M -- python3 $TA --steps 5 --warmup 2 > "$OUT/train_bf16x3_${M}_stats.log" 2>&1
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_train_bf16x3_a16_$c" -o train_bf16x3_a16 -- python3 $TA --steps 1 --warmup 1 > "$OUT/pmc_train_bf16x3_a16_$c.log" 2>&1
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_train_bf16x3_${M}_$c" -o train_bf16x3_$M -- python3 $TA --steps 1 --warmup 1 > "$OUT/pmc_train_bf16x3_${M}_$c.log" 2>&1
       done
-      timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_train_bf16x3_a16_sq" -o train_bf16x3_a16 -- python3 $TA --steps 2 --warmup 1 > "$OUT/pmc_train_bf16x3_a16_sq.log" 2>&1 ;;
+      timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_train_bf16x3_${M}_sq" -o train_bf16x3_$M -- python3 $TA --steps 2 --warmup 1 > "$OUT/pmc_train_bf16x3_${M}_sq.log" 2>&1 ;;
     stats_train)
       timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_train" -o train -- python3 $TRAIN --no-extras > "$OUT/train_stats.log" 2>&1
       head -6 "$OUT"/stats_train/train_kernel_stats.csv | cut -c1-150 ;;
