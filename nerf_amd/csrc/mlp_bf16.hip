@@ -16,6 +16,8 @@
 // Inference only; training stays on the exact f32 kernels.
 #include "mlp_device.h"
 #include <stdlib.h>
+#include <utility>
+#include <type_traits>
 
 namespace nrf {
 
@@ -302,6 +304,7 @@ __device__ __forceinline__ uint32_t pack2h(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2));
 }
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t sat2h(uint32_t p) {      // p: two non-negative f16 patterns
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, p), (u16x2){0x7BFF, 0x7BFF}));
 }
@@ -334,8 +337,10 @@ struct WStreamT {
     // one of the four 1 KiB pieces this wave copies per chunk; the ring position advances after the last one
     __device__ __forceinline__ void request_piece(int i) {
         const uint32_t f = (uint32_t)wave + 4 * i;
+#ifndef NRF_EXP_NODMA       // (timing experiments: results are wrong with any NRF_EXP_* macro)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + st_req + f * kFrag),
                                                  16, lane16, (int)(pf_off + f * kFrag), 0, 0);
+#endif
         if (i == 3) {
             pf_off += kChunk;
             if (pf_off == total) pf_off = 0;
@@ -359,6 +364,9 @@ struct WStreamT {
     __device__ __forceinline__ void publish() {
         // the copies of chunks beyond the next one (4 per chunk and wave, returned in order) may stay in flight
         static_assert((kStages - 3) * 4 + YOUNGER <= 63, "vmcnt is a 6-bit counter");
+#ifdef NRF_EXP_NOBAR
+        return;
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 3) * 4 + YOUNGER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -369,6 +377,9 @@ struct WStreamT {
         if (rd_nxt >= (uint32_t)(kStages * kChunk)) rd_nxt -= kStages * kChunk;
     }
     __device__ __forceinline__ bf16x8 read(bool nxt, int f) const {
+#ifdef NRF_EXP_NOLDS
+        { bf16x8 v = q[f % AHEAD]; asm volatile("" : "+v"(v)); return v; }     // no LDS read, no register write, opaque
+#endif
         return *reinterpret_cast<const bf16x8 *>(lds + (nxt ? rd_nxt : rd_cur) + f * kFrag);
     }
     __device__ __forceinline__ void start() {
@@ -781,27 +792,36 @@ __device__ __forceinline__ void store_tile_t8_quads(__amdgpu_buffer_rsrc_t rsrc,
 // points of one channel are two packed f16 pairs -- one 8-byte store.  nonneg: the values went through a ReLU, so the
 // saturation at 65504 (an infinity among the saved activations would turn a weight gradient into NaN) is one unsigned
 // 16-bit min per pair; the one section without a ReLU (feature_linear) clamps in f32 first.
+__device__ __forceinline__ void quad_transpose_h_step1(uint32_t &p0, uint32_t &p1, bool o2);
+__device__ __forceinline__ void quad_transpose_h_step2(uint32_t &p0, uint32_t &p1, uint32_t sel);
+__device__ __forceinline__ uint32_t quad_transpose_h_sel(int lane);
 __device__ __forceinline__ void store_tile_t8_quads_h(__amdgpu_buffer_rsrc_t rsrc, int lane, int C, uint32_t sec, int t,
                                                       const float (&r)[16], bool nonneg) {
     const int q = lane & 31, h = lane >> 5;
     const int voff = (((q >> 3) * C + 4 * h + (q & 3)) * 8 + (q & 4)) * 2;
+    const bool o2 = lane & 2;
+    const uint32_t sel = quad_transpose_h_sel(lane);
+    uint32_t p[8];
+    // convert first (this lane's point, channel pairs), then transpose the PACKED pairs inside the lane quad: 8 operations a
+    // group where the f32 transpose took 16
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        uint32_t a[4] = {__float_as_uint(r[4 * g]), __float_as_uint(r[4 * g + 1]), __float_as_uint(r[4 * g + 2]),
-                         __float_as_uint(r[4 * g + 3])};
-        quad_transpose(a, lane);
-        uint32_t p0, p1;
         if (nonneg) {
-            p0 = sat2h(pack2h(__uint_as_float(a[0]), __uint_as_float(a[1])));
-            p1 = sat2h(pack2h(__uint_as_float(a[2]), __uint_as_float(a[3])));
+            p[2 * g] = sat2h(pack2h(r[4 * g], r[4 * g + 1]));
+            p[2 * g + 1] = sat2h(pack2h(r[4 * g + 2], r[4 * g + 3]));
         } else {
-            p0 = pack2h(__builtin_amdgcn_fmed3f(__uint_as_float(a[0]), -65504.0f, 65504.0f),
-                        __builtin_amdgcn_fmed3f(__uint_as_float(a[1]), -65504.0f, 65504.0f));
-            p1 = pack2h(__builtin_amdgcn_fmed3f(__uint_as_float(a[2]), -65504.0f, 65504.0f),
-                        __builtin_amdgcn_fmed3f(__uint_as_float(a[3]), -65504.0f, 65504.0f));
+            p[2 * g] = pack2h(__builtin_amdgcn_fmed3f(r[4 * g], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(r[4 * g + 1], -65504.0f, 65504.0f));
+            p[2 * g + 1] = pack2h(__builtin_amdgcn_fmed3f(r[4 * g + 2], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(r[4 * g + 3], -65504.0f, 65504.0f));
         }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) quad_transpose_h_step1(p[2 * g], p[2 * g + 1], o2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) quad_transpose_h_step2(p[2 * g], p[2 * g + 1], sel);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
         typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
-        const u32x2s v = {p0, p1};
+        const u32x2s v = {p[2 * g], p[2 * g + 1]};
         __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, (int)(sec * 4 + (32 * t + 8 * g) * 8 * 2), 0);
     }
 }
@@ -841,10 +861,6 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[k]), sv->tb.rsrc, voff,
                                                       (int)((sec + (32 * t + 8 * (k >> 2) + (k & 3)) * 8) * 4), 0);
 #endif
-            if (gate_slot >= 0) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) gm[t >> 1] = (gm[t >> 1] << 1) | min(__float_as_uint(r[k]), 1u);
-            }
         }
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
@@ -853,15 +869,344 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
             hh[2 * t + (w >> 2)][w & 3] = hi;
             hl[2 * t + (w >> 2)][w & 3] = lo;
         }
+        if constexpr (TRAIN) {
+            // gate bit = the value's leading bf16 is non-zero (h > 0 after the ReLU): one packed min and one dot product per
+            // PAIR, the dot's 16-bit weights being the pair's bit positions (store_gate_bits' order) -- half the operations of
+            // a min and a shift-or per value
+            if (gate_slot >= 0) {
+                uint32_t bits = (t & 1) ? gm[t >> 1] : 0u;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const u16x2v m = __builtin_elementwise_min(__builtin_bit_cast(u16x2v, (uint32_t)hh[2 * t + (w >> 2)][w & 3]), (u16x2v){1, 1});
+                    bits = __builtin_amdgcn_udot2(m, (u16x2v){(unsigned short)(1u << (15 - 2 * w)), (unsigned short)(1u << (14 - 2 * w))}, bits, false);
+                }
+                gm[t >> 1] = (t & 1) ? bits : (bits << 16);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (TRAIN) {
         if (gate_slot >= 0) {
-            if constexpr (NT & 1) gm[NT >> 1] <<= 16;
             u32x4 v = {gm[0], gm[1], gm[2], gm[3]};
             buffer_store_b128(v, sv->tb.rsrc, sv->lane * 16, gate_slot * 4);
         }
     }
+}
+
+// ---- conversion UNDER the next GEMM ("piped" layers) ---------------------------------------------------------------------
+// Between two GEMMs of the chain a wave has ~150-200 VALU operations per 32-channel tile to do (accumulator reads, ReLU,
+// hi/residual split; in training also the gate bits, the f16 conversion, a transpose and the store), and with one wave per
+// SIMD nothing else runs meanwhile: the matrix pipe idled through 26 % (inference) to 48 % (training) of these kernels.
+// But k-steps 2t, 2t+1 of the next GEMM only need tile t of this one.  So the next GEMM keeps its OWN accumulator set (two sets
+// = all 256 accumulation registers), starts as soon as tile 0 is converted, and tile t+1 is converted in micro-slices of <= 6
+// VALU operations placed after each of the 6 * NT_OUT MFMAs that consume tile t (measured: six independent VALU operations
+// fit under a 32x32x16 MFMA at no cost, `scratch/mfma_fill.hip`).  Only tile 0's conversion stays exposed (hidden layers) or
+// runs under the encoded-input k-steps (skip layer).
+#ifndef NRF_X3_PIPE
+#define NRF_X3_PIPE 0
+#endif
+constexpr int kConvSlices = 48;      // per tile: 4 register groups x 12 stages
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+
+// the quad transpose of quad_transpose() in four parts of four operations (part 0, 1: first round; 2, 3: second round)
+__device__ __forceinline__ void quad_transpose_part(uint32_t (&a)[4], bool o1, bool o2, int part) {
+    if (part < 2) {
+        const int p = 2 * part;
+        const uint32_t s = o1 ? a[p] : a[p + 1];
+        const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0xB1, 0xF, 0xF, true);
+        a[p] = o1 ? got : a[p];
+        a[p + 1] = o1 ? a[p + 1] : got;
+    } else {
+        const int p = part - 2;
+        const uint32_t s = o2 ? a[p] : a[p + 2];
+        const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4E, 0xF, 0xF, true);
+        a[p] = o2 ? got : a[p];
+        a[p + 2] = o2 ? a[p + 2] : got;
+    }
+}
+
+// The 4x4 transpose of a lane quad on PACKED 16-bit pairs (lane i: p0 = channels 0, 1, p1 = channels 2, 3 of its point ->
+// p0 = points 0, 1, p1 = points 2, 3 of channel i): a dword exchange with lane i ^ 2, then a half-word exchange with lane
+// i ^ 1 through v_perm_b32 -- 8 operations where the f32 transpose followed by the conversion takes 16.
+__device__ __forceinline__ void quad_transpose_h_step1(uint32_t &p0, uint32_t &p1, bool o2) {
+    const uint32_t s = o2 ? p0 : p1;
+    const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    p0 = o2 ? got : p0;
+    p1 = o2 ? p1 : got;
+}
+__device__ __forceinline__ void quad_transpose_h_step2(uint32_t &p0, uint32_t &p1, uint32_t sel) {
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    const uint32_t g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0xB1, 0xF, 0xF, true);
+    p0 = __builtin_amdgcn_perm(g0, p0, sel);
+    p1 = __builtin_amdgcn_perm(g1, p1, sel);
+}
+__device__ __forceinline__ uint32_t quad_transpose_h_sel(int lane) { return (lane & 1) ? 0x03020706u : 0x05040100u; }
+
+// State of a forward conversion across its micro-slices (registers; only one or two groups' worth is live at a time).
+// TRAIN as in pack_acts_x3; RELU: the layer has one; GATE: its gate bits are saved (training).
+template <int TRAIN, bool RELU, bool GATE>
+struct ConvFwd {
+    static constexpr int kTrain = TRAIN;
+    static constexpr bool kGate = GATE && TRAIN != 0;
+    static constexpr int kStoreStage = TRAIN == 2 ? 10 : 11;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t sec;        // T8 section (floats from the tile base)
+    uint32_t gate_slot;
+    int C;               // channels of the section
+    int lane, voff;
+    bool o1, o2;
+    uint32_t sel;
+    float r[16], ta[4], tb[4];
+    uint32_t p[8], gm[4], bits;
+
+    __device__ __forceinline__ void init(const X3Save *sv, uint32_t sec_, int gate_slot_, int C_) {
+        if constexpr (TRAIN != 0) {
+            rsrc = sv->tb.rsrc;
+            lane = sv->lane;
+            const int q = lane & 31, h = lane >> 5;
+            voff = (((q >> 3) * C_ + 4 * h + (q & 3)) * 8 + (q & 4)) * (TRAIN == 2 ? 2 : 4);
+            o1 = lane & 1; o2 = lane & 2;
+            sel = quad_transpose_h_sel(lane);
+            sec = sec_;
+            asm volatile("" : "+s"(sec));
+            gate_slot = (uint32_t)gate_slot_;
+            gm[0] = gm[1] = gm[2] = gm[3] = 0u;
+        }
+        C = C_;
+    }
+    template <int G>
+    __device__ __forceinline__ void relu4() {
+        if constexpr (RELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[4 * G + k]) : "v"(r[4 * G + k]));
+        }
+    }
+    template <int G>
+    __device__ __forceinline__ void cvt_h(uint32_t &p0, uint32_t &p1) {
+        if constexpr (RELU) {
+            p0 = sat2h(pack2h(r[4 * G], r[4 * G + 1]));
+            p1 = sat2h(pack2h(r[4 * G + 2], r[4 * G + 3]));
+        } else {
+            p0 = pack2h(__builtin_amdgcn_fmed3f(r[4 * G], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(r[4 * G + 1], -65504.0f, 65504.0f));
+            p1 = pack2h(__builtin_amdgcn_fmed3f(r[4 * G + 2], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(r[4 * G + 3], -65504.0f, 65504.0f));
+        }
+    }
+    // stores issued by micro-slice u of tile T (of NT_IN tiles)
+    static constexpr int stores(int T, int u, int NT_IN) {
+        if (TRAIN == 0) return 0;
+        return (u % 12 == kStoreStage ? 1 : 0) + (kGate && T == NT_IN - 1 && u == kConvSlices - 1 ? 1 : 0);
+    }
+    static constexpr int stores_per_tile() { return TRAIN == 0 ? 0 : 4; }
+};
+
+// micro-slice U (0..47) of the conversion of accumulator tile T into operand k-steps 2T, 2T+1 (hh, hl).  T and U are template
+// arguments: every register index below must be a constant in the front end already (left to the optimiser, the operand
+// arrays went to scratch memory)
+template <int NT, int T, int U, class CV>
+__device__ __forceinline__ void conv_slice(CV &c, u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT], const f32x16 (&acc)[NT]) {
+    constexpr int TRAIN = CV::kTrain;
+    constexpr int g = U / 12, stg = U % 12;
+    if constexpr (stg == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c.r[4 * g + k]) : "a"(acc[T][4 * g + k]));
+    } else if constexpr (stg == 1) {
+        c.template relu4<g>();
+    } else if constexpr (stg >= 2 && stg <= 5) {
+        constexpr int q = (stg - 2) >> 1, w = 2 * g + q;
+        if constexpr (((stg - 2) & 1) == 0) {
+            const uint32_t hi = pack2(c.r[4 * g + 2 * q], c.r[4 * g + 2 * q + 1]);
+            hh[2 * T + (w >> 2)][w & 3] = hi;
+            c.ta[g] = __uint_as_float(hi << 16);
+            c.tb[g] = __uint_as_float(hi & 0xffff0000u);
+        } else {
+            hl[2 * T + (w >> 2)][w & 3] = pack2(c.r[4 * g + 2 * q] - c.ta[g], c.r[4 * g + 2 * q + 1] - c.tb[g]);
+        }
+    } else if constexpr (stg == 6) {
+        if constexpr (CV::kGate) {
+            // gate bit = the value's leading bf16 is non-zero (h > 0): one packed min and one dot product per PAIR, the
+            // dot's 16-bit weights being the pair's bit positions (tile t, register k -> dword t >> 1, bit 31 - (16 (t & 1) + k))
+            if constexpr (g == 0) c.bits = (T & 1) ? c.gm[T >> 1] : 0u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int w = 2 * g + q;
+                const u16x2v m = __builtin_elementwise_min(__builtin_bit_cast(u16x2v, (uint32_t)hh[2 * T + (w >> 2)][w & 3]), (u16x2v){1, 1});
+                c.bits = __builtin_amdgcn_udot2(m, (u16x2v){(unsigned short)(1u << (15 - 2 * w)), (unsigned short)(1u << (14 - 2 * w))},
+                                                c.bits, false);
+            }
+            if constexpr (g == 3) c.gm[T >> 1] = (T & 1) ? c.bits : (c.bits << 16);
+        }
+    } else if constexpr (TRAIN == 2) {
+        uint32_t &p0 = c.p[2 * g], &p1 = c.p[2 * g + 1];
+        if constexpr (stg == 7) {
+            c.template cvt_h<g>(p0, p1);
+        } else if constexpr (stg == 8) {
+            quad_transpose_h_step1(p0, p1, c.o2);
+        } else if constexpr (stg == 9) {
+            quad_transpose_h_step2(p0, p1, c.sel);
+        } else if constexpr (stg == 10) {
+            typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+            const u32x2s v = {p0, p1};
+            __builtin_amdgcn_raw_buffer_store_b64(v, c.rsrc, c.voff, (int)(c.sec * 4 + (32 * T + 8 * g) * 8 * 2), 0);
+        }
+    } else if constexpr (TRAIN == 1) {
+        uint32_t a[4] = {__float_as_uint(c.r[4 * g]), __float_as_uint(c.r[4 * g + 1]), __float_as_uint(c.r[4 * g + 2]),
+                         __float_as_uint(c.r[4 * g + 3])};
+        if constexpr (stg <= 10) {
+            quad_transpose_part(a, c.o1, c.o2, stg - 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c.r[4 * g + k] = __uint_as_float(a[k]);
+        } else {
+            const u32x4 v = {a[0], a[1], a[2], a[3]};
+            buffer_store_b128(v, c.rsrc, c.voff, (int)((c.sec + (32 * T + 8 * g) * 8) * 4));
+        }
+    }
+    if constexpr (CV::kGate && U == kConvSlices - 1 && T == NT - 1) {
+        const u32x4 v = {c.gm[0], c.gm[1], c.gm[2], c.gm[3]};
+        buffer_store_b128(v, c.rsrc, c.lane * 16, (int)(c.gate_slot * 4));
+    }
+}
+
+// Where the micro-slices of a piped GEMM sit.  The GEMM has S_PRE k-steps that do not depend on the conversion (encoded
+// inputs of the skip layer), then the 2 * NT_IN k-steps of the converted tiles, then S_POST (bias).  MFMA e (0, 1: the hi
+// fragment's two; 2: the residual fragment's) of k-step s, output tile t is followed by the slices [lo, hi) of tile T:
+//   pre region (S_PRE > 0): tile 0 spread evenly over its 3 * S_PRE * NT_OUT MFMAs;
+//   k-steps of tile T - 1: tile T spread evenly over their 6 * NT_OUT MFMAs.
+template <int NT_OUT, int NT_IN, int S_PRE>
+struct ConvMap {
+    int T, lo, hi;
+    constexpr ConvMap(int s, int t, int e) : T(0), lo(0), hi(0) {
+        if (S_PRE > 0 && s < S_PRE) {
+            const int M = 3 * (S_PRE > 0 ? S_PRE : 1) * NT_OUT, mo = 3 * (s * NT_OUT + t) + e;
+            T = 0; lo = mo * kConvSlices / M; hi = (mo + 1) * kConvSlices / M;
+        } else {
+            const int hs = s - S_PRE, M = 6 * NT_OUT;
+            if (hs / 2 + 1 < NT_IN) {
+                const int mo = (hs & 1) * 3 * NT_OUT + 3 * t + e;
+                T = hs / 2 + 1; lo = mo * kConvSlices / M; hi = (mo + 1) * kConvSlices / M;
+            }
+        }
+    }
+};
+// stores issued in the bodies of fragments [0, frag) of such a GEMM (fragment i: pair i >> 1 = (s, t); even: MFMAs 0, 1; odd: 2)
+template <class CV, int NT_OUT, int NT_IN, int S_PRE>
+struct ConvStores {
+    static constexpr int exposed = S_PRE == 0 ? CV::stores_per_tile() : 0;   // tile 0's, issued just before fragment 0
+    static constexpr int before(int frag) {
+        int n = 0;
+        for (int i = 0; i < frag; ++i) {
+            const int j = i >> 1, s = j / NT_OUT, t = j % NT_OUT;
+            for (int e = (i & 1) ? 2 : 0; e < ((i & 1) ? 3 : 2); ++e) {
+                const ConvMap<NT_OUT, NT_IN, S_PRE> m(s, t, e);
+                for (int u = m.lo; u < m.hi; ++u) n += CV::stores(m.T, u, NT_IN);
+            }
+        }
+        return n;
+    }
+};
+struct NoStores {
+    static constexpr int exposed = 0;
+    static constexpr int before(int) { return 0; }
+};
+
+// stream_frags with the store allowance of every publish computed from SC (stores issued by the bodies, per fragment): at the
+// publish of chunk c the awaited copies are those of chunk c + 1, requested two chunks earlier; every store issued since the
+// last of them may stay in flight beside the four copies of chunk c + 2.  In a layer's first two chunks those copies were
+// requested before the layer began: all of its stores so far, and the `exposed` ones just before it, are younger.
+template <int N, class SC, class ST, class Body>
+__device__ __forceinline__ void stream_frags_sc(ST &st, Body &&body) {
+    constexpr int kAhead = ST::kDepth;
+    static_assert(kStages == 4, "the store allowance assumes copies two chunks ahead");
+    static_assert(N % kAhead == 0 && N >= kAhead, "fragment count of a layer must be a multiple of the read-ahead");
+    static_assert(N % 16 == 0 || N % 16 >= kAhead, "a layer's last chunk must hold at least the read-ahead");
+    constexpr int NCH = (N + 15) / 16;
+    static_for<NCH>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        constexpr int F = (N - 16 * c) < 16 ? (N - 16 * c) : 16;          // fragments in this chunk
+        constexpr int pos = (F / 2 < F - kAhead) ? F / 2 : F - kAhead;    // publish before the first read of the next chunk
+        constexpr int span = F - pos, stp = span >= 8 ? 2 : 1;
+        // chunk c - 2 is a full one: its publish at 8, its copy requests at 8, 10, 12, 14
+        constexpr int pos2 = (8 < 16 - kAhead) ? 8 : 16 - kAhead;
+        constexpr int last2 = (16 - pos2 >= 8) ? pos2 + 6 : ((16 - pos2 >= 4) ? pos2 + 3 : pos2);
+        constexpr int young = c >= 2 ? SC::before(16 * c + pos) - SC::before(16 * (c - 2) + last2)
+                                     : SC::exposed + SC::before(16 * c + pos);
+        static_for<F>([&](auto f_) {
+            constexpr int f = decltype(f_)::value, i = 16 * c + f;
+            if constexpr (f == pos) st.template publish<young>();
+            if constexpr (span >= 4) {
+                if constexpr (f >= pos && (f - pos) % stp == 0 && (f - pos) / stp < 4) st.request_piece((f - pos) / stp);
+            } else if constexpr (f == pos) {
+                st.request();
+            }
+            const bf16x8 a = st.q[i % kAhead];
+            {
+                constexpr int j = i + kAhead;
+                if constexpr (j < N) st.q[i % kAhead] = st.read((j >> 4) != c, j & 15);
+                else st.q[i % kAhead] = st.read(true, j - N);          // the next layer's first fragments
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            body(f_, std::integral_constant<int, i>{}, a);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        st.rotate();
+    });
+}
+
+// gemm_layer_x3 with the conversion of its hidden input (accumulator tiles `src` -> hh, hl, by `cv`) running under its own
+// MFMAs.  k-steps: S_PRE from (PreH, PreL), then hh/hl[0 .. 2 NT_IN), then the bias step if BIAS_LAST.
+template <int NT_OUT, int NT_IN, int S_PRE, bool BIAS_LAST, class CV, class PH, class PL>
+__device__ __forceinline__ void gemm_layer_x3_conv(f32x16 (&acc)[NT_OUT], WStreamX3 &st, CV &cv, u32x4v (&hh)[2 * NT_IN],
+                                                   u32x4v (&hl)[2 * NT_IN], const f32x16 (&src)[NT_IN], PH &&PreH, PL &&PreL,
+                                                   const u32x4v &one, const u32x4v &none) {
+    constexpr int S = S_PRE + 2 * NT_IN + (BIAS_LAST ? 1 : 0);
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (S_PRE == 0) {
+        // tile 0: nothing to run under; four groups interleaved (a dependent VALU chain issues at a third of the rate)
+        static_for<12>([&](auto stg_) {
+            static_for<4>([&](auto g_) { conv_slice<NT_IN, 0, 12 * decltype(g_)::value + decltype(stg_)::value>(cv, hh, hl, src); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    auto B = [&](auto s_, auto lo_) -> bf16x8 {
+        constexpr int s = decltype(s_)::value;
+        constexpr bool lo = decltype(lo_)::value;
+        if constexpr (s < S_PRE) return lo ? PreL(s) : PreH(s);
+        else if constexpr (s < S_PRE + 2 * NT_IN) return as_bf(lo ? hl[s - S_PRE] : hh[s - S_PRE]);
+        else return as_bf(lo ? none : one);
+    };
+    auto fill = [&](auto s_, auto t_, auto e_) {
+        constexpr ConvMap<NT_OUT, NT_IN, S_PRE> m(decltype(s_)::value, decltype(t_)::value, decltype(e_)::value);
+        constexpr int T = m.T, lo = m.lo, n = m.hi - m.lo;
+        static_for<n>([&](auto k_) { conv_slice<NT_IN, T, lo + decltype(k_)::value>(cv, hh, hl, src); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using std::integral_constant;
+    stream_frags_sc<2 * S * NT_OUT, ConvStores<CV, NT_OUT, NT_IN, S_PRE>>(st, [&](auto, auto i_, const bf16x8 &a) {
+        constexpr int i = decltype(i_)::value, j = i >> 1, s = j / NT_OUT, t = j % NT_OUT;
+        const integral_constant<int, s> sc;
+        const integral_constant<int, t> tc;
+        if constexpr ((i & 1) == 0) {
+            if constexpr (s == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(sc, std::false_type{}), zero, 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(sc, std::false_type{}), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(sc, tc, integral_constant<int, 0>{});
+            if constexpr (!(BIAS_LAST && s == S - 1)) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(sc, std::true_type{}), acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fill(sc, tc, integral_constant<int, 1>{});
+            }
+        } else {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B(sc, std::false_type{}), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(sc, tc, integral_constant<int, 2>{});
+        }
+    });
 }
 
 // gamma(v) of a 3-vector (slot order of bf_pe3_chan), every frequency by an accurate sincos (nrf_sincos): the recurrence of
@@ -947,6 +1292,39 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
     }
 }
 
+// The trunk with every layer after the first converting its input under its own MFMAs (gemm_layer_x3_conv): the layers
+// alternate between two accumulator sets; the last layer's output is converted in the open (the heads follow).
+template <int NT, int S0, int TRAIN = 0, class B0H, class B0L>
+__device__ __forceinline__ void bf_trunk_x3_piped(f32x16 (&acc)[NT], f32x16 (&accB)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
+                                                  const u32x4v (&xh)[kBfKsX], const u32x4v (&xl)[kBfKsX], const u32x4v &one,
+                                                  const u32x4v &none, WStreamX3 &st, int n_trunk, int skip_in_mask, B0H &&b0h,
+                                                  B0L &&b0l, const X3Save *sv = nullptr, uint32_t a_trunk = 0, int a_mask = 0) {
+    gemm_layer_x3<NT, S0>(acc, st, b0h, b0l);
+    constexpr uint32_t kSec = (TRAIN == 2 ? 16 : 32) * 32 * NT;
+    auto layer = [&](f32x16 (&out)[NT], const f32x16 (&in)[NT], int l) __attribute__((always_inline)) {
+        ConvFwd<TRAIN, true, true> cv;
+        cv.init(sv, a_trunk + (uint32_t)(l - 1) * kSec, a_mask + (l - 1) * 256, 32 * NT);
+        if ((skip_in_mask >> l) & 1)
+            gemm_layer_x3_conv<NT, NT, kBfKsX, false>(
+                out, st, cv, hh, hl, in, [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); }, one, none);
+        else
+            gemm_layer_x3_conv<NT, NT, 0, true>(
+                out, st, cv, hh, hl, in, [&](int) { return as_bf(one); }, [&](int) { return as_bf(none); }, one, none);
+    };
+    int l = 1;
+    for (; l + 1 < n_trunk; l += 2) {
+        layer(accB, acc, l);
+        layer(acc, accB, l + 1);
+    }
+    const uint32_t sec_last = a_trunk + (uint32_t)(n_trunk - 1) * kSec;
+    if (l < n_trunk) {
+        layer(accB, acc, l);
+        pack_acts_x3<NT, TRAIN>(hh, hl, accB, true, sv, sec_last, a_mask + (n_trunk - 1) * 256);
+    } else {
+        pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, sec_last, a_mask + (n_trunk - 1) * 256);
+    }
+}
+
 // View-direction head in bf16x3 (network.py:56-65) -> (rgb, alpha) of the wave's point tile, stored by lane half 0.
 template <int NT, int TRAIN = 0>
 __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * NT], u32x4v (&hl)[2 * NT],
@@ -1029,9 +1407,16 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
         }
         f32x16 acc[NT];
         u32x4v hh[2 * NT], hl[2 * NT];
+#if NRF_X3_PIPE
+        f32x16 accB[NT];
+        bf_trunk_x3_piped<NT, kBfKsX, TRAIN>(acc, accB, hh, hl, xh, xl, one, none, st, a.n_trunk, a.skip_in_mask,
+                                             [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); },   // network.py:48-53
+                                             svp, (uint32_t)a.tl.a_trunk, (int)a.tl.a_mask);
+#else
         bf_trunk_x3<NT, kBfKsX, TRAIN>(acc, hh, hl, xh, xl, one, none, st, a.n_trunk, a.skip_in_mask,
                                        [&](int s) { return as_bf(xh[s]); }, [&](int s) { return as_bf(xl[s]); },   // network.py:48-53
                                        svp, (uint32_t)a.tl.a_trunk, (int)a.tl.a_mask);
+#endif
         if constexpr (VIEWS) {
             bf_views_head_x3<NT, TRAIN>(acc, hh, hl, dh, dl, one, none, st, hb, pp, a.n_points, h, a.raw, svp,
                                         (uint32_t)a.tl.a_feat, (uint32_t)a.tl.a_hv, (int)a.tl.a_mask + a.n_trunk * 256);
