@@ -900,7 +900,7 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
 // But k-steps 2t, 2t+1 of the next GEMM only need tile t of this one.  So the next GEMM keeps its OWN accumulator set (two sets
 // = all 256 accumulation registers), starts as soon as tile 0 is converted, and tile t+1 is converted in micro-slices of <= 6
 // VALU operations placed after each of the 6 * NT_OUT MFMAs that consume tile t (measured: six independent VALU operations
-// fit under a 32x32x16 MFMA at no cost, `scratch/mfma_fill.hip`).  Only tile 0's conversion stays exposed (hidden layers) or
+// fit under a 32x32x16 MFMA at no cost, `scripts/microbench/mfma_fill.hip`, `profiles/r3_mfma_fill_microbench.txt`).  Only tile 0's conversion stays exposed (hidden layers) or
 // runs under the encoded-input k-steps (skip layer).
 #ifndef NRF_X3_PIPE
 #define NRF_X3_PIPE 0
