@@ -822,7 +822,11 @@ __device__ __forceinline__ void store_tile_t8_quads_h(__amdgpu_buffer_rsrc_t rsr
     for (int g = 0; g < 4; ++g) {
         typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
         const u32x2s v = {p[2 * g], p[2 * g + 1]};
+#ifdef NRF_EXP_NOSTORE      // timing experiment: the conversion without its stores
+        asm volatile("" ::"v"(v));
+#else
         __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, (int)(sec * 4 + (32 * t + 8 * g) * 8 * 2), 0);
+#endif
     }
 }
 

@@ -1,14 +1,16 @@
 #!/bin/bash
 # A/B of library variants on ONE box (run through gpurun): build variants into scratch/<name>.so, then
 #   bash scripts/ab_variants.sh a.so b.so      -> per-kernel ms per training step from rocprofv3 stats, two rounds
+#   AB_ARGS='--train-precision bf16x3_w16' picks the step's arithmetic; 'orig' = the library in the tree
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+cp $R/nerf_amd/libnrf.so /tmp/libnrf_orig.so
 for round in 1 2; do
 for v in "$@"; do
-  cp $R/scratch/$v $R/nerf_amd/libnrf.so
+  if [ $v = orig ]; then cp /tmp/libnrf_orig.so $R/nerf_amd/libnrf.so; else cp $R/scratch/$v $R/nerf_amd/libnrf.so; fi
   rm -rf /tmp/ab_$v
-  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -o t -- python3 $R/bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /tmp/ab_$v.log 2>&1
+  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -o t -- python3 $R/bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-extras $AB_ARGS > /tmp/ab_$v.log 2>&1
   python3 - "$v" /tmp/ab_$v/t_kernel_stats.csv <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[2])):

@@ -306,6 +306,18 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
                 assert e <= 1e-2, (mag, k, e)
         print(f"w16 {cfg} (|g_raw| x {mag:g}): gradients within {worst_f:.1e} of their norm ({worst:.1e} of their largest "
               "element) of the f32-workspace bf16x3 backward")
+    # an all-zero incoming gradient (scale 1, nothing to divide by): every gradient exactly zero; and ONE non-zero point among
+    # zeros: the scale comes from that point, the pass stays finite and agrees with the f32-workspace pass
+    grads_0 = f32.query_bwd(torch.zeros_like(g_raw), P, acts_c, x3=True, a16="w16")
+    assert all(bool((v == 0).all()) for v in grads_0.values())
+    g_one = torch.zeros_like(g_raw)
+    g_one[P // 2] = g_raw[P // 2]
+    grads_ref = f32.query_bwd(g_one, P, acts_b, x3=True)
+    grads_w = f32.query_bwd(g_one, P, acts_c, x3=True, a16="w16")
+    for k in grads_ref:
+        assert bool(torch.isfinite(grads_w[k]).all()), k
+        ef = float((grads_ref[k] - grads_w[k]).double().norm()) / max(float(grads_ref[k].double().norm()), 1e-30)
+        assert ef <= 3e-3, (k, ef)
 
 
 @pytest.mark.parametrize("train_precision", TRAIN_PRECISIONS)
