@@ -375,7 +375,8 @@ def test_query_point_gradients(train_precision, views, W, D, skips, n, ppr):
             net.query_points(pts.detach(), dirs.clone().requires_grad_(True), ppr, L, Lv)
 
 
-@pytest.mark.parametrize("train_precision,W", [("fp32", 64), ("fp32", 256), ("bf16x3", 128)])
+@pytest.mark.parametrize("train_precision,W", [("fp32", 64), ("fp32", 256), ("bf16x3", 128), ("bf16x3_a16", 128),
+                                               ("bf16x3_w16", 256), ("bf16x3_w16", 128)])
 def test_deep_net_with_several_skips(train_precision, W):
     """D = 16 with three skip layers (the deepest net the kernels take; network.py:29-53): 19 weight-gradient GEMMs and more
     slab reductions than one batched launch holds, so the backward flushes its queues mid-pass.  Parameter gradients against
