@@ -62,3 +62,23 @@ def render_kwargs(args, query_fn, coarse, fine, **extra):
     train.update(extra)
     test = dict(train, perturb=False, raw_noise_std=0.)
     return train, test
+
+
+# Arithmetic of the fused kernels, chosen without touching the reference's drivers: an `args.precision` /
+# `args.train_precision` attribute if the caller's parser has one (ours to add: the reference's config.py has no such flag),
+# else the environment (NRF_PRECISION, NRF_TRAIN_PRECISION).  Unset = the exact f32 kernels.
+def apply_precision(args, *modules):
+    chosen = {}
+    for attr, env in (("precision", "NRF_PRECISION"), ("train_precision", "NRF_TRAIN_PRECISION")):
+        v = getattr(args, attr, None) or os.environ.get(env)
+        if v:
+            chosen[attr] = str(v)
+    for m in modules:
+        if m is None:
+            continue
+        for attr, v in chosen.items():
+            allowed = getattr(m, f"{attr}_choices", None)
+            if allowed is not None and v not in allowed:
+                raise ValueError(f"{attr} {v!r} is not one of {sorted(allowed)} for {type(m).__name__}")
+            setattr(m, attr, v)
+    return chosen

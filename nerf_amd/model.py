@@ -21,6 +21,7 @@ def create_nerf(args):
 
     coarse = net(args.netdepth, args.netwidth)
     fine = net(args.netdepth_fine, args.netwidth_fine) if two_pass else None
+    _setup.apply_precision(args, coarse, fine)
     grad_vars = [p for m in (coarse, fine) if m is not None for p in m.parameters()]
 
     def network_query_fn(inputs, viewdirs, network_fn):

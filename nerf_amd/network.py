@@ -73,6 +73,9 @@ class _QueryFunction(torch.autograd.Function):
 
 
 class NeRF(nn.Module):
+    precision_choices = ("fp32", "bf16", "f16", "bf16x3")                            # inference arithmetic (`precision`)
+    train_precision_choices = ("fp32", "bf16x3", "bf16x3_a16", "bf16x3_w16")        # training arithmetic
+
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super().__init__()
         self.D, self.W = D, W

@@ -41,6 +41,7 @@ def create_dnerf(args):
     # one deformation model serves both passes unless asked otherwise (model.py:93-104)
     own_fine = two_pass and (straight or getattr(args, 'use_two_models_for_fine', False))
     fine = net(args.netdepth_fine, args.netwidth_fine) if own_fine else None
+    _setup.apply_precision(args, coarse, fine)
     grad_vars = [p for m in (coarse, fine) if m is not None for p in m.parameters()]
 
     def network_query_fn(inputs, viewdirs, times, network_fn):

@@ -184,6 +184,9 @@ class DNeRF_Straightforward(nn.Module):
     embedded rows (nrf_dnerf_straight_query_fwd, embed mode 1); with gradients, or for shapes the kernel does not take, the
     same arithmetic composed from GPU torch ops.  Both pinned to the reference's outputs (tests/golden/dnerf2.npz)."""
 
+    precision_choices = ("fp32", "bf16", "bf16x3")
+    train_precision_choices = ("fp32",)
+
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, input_ch_time=1, output_ch=4, skips=[4],
                  use_viewdirs=True):
         super().__init__()
@@ -285,6 +288,9 @@ _TWO_LAUNCH_POINTS = 65536      # points per time-net launch of the two-launch i
 
 
 class DNeRF_Deformation(nn.Module):
+    precision_choices = ("fp32", "bf16", "bf16x3")
+    train_precision_choices = ("fp32", "bf16x3")
+
     def __init__(self, D=8, W=256, D_deform=8, W_deform=256, input_ch=3, input_ch_views=3, input_ch_time=1,
                  output_ch=4, skips=[4], skips_deform=[4], use_viewdirs=True, zero_canonical=True,
                  use_layernorm=False):

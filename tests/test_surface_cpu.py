@@ -68,3 +68,30 @@ def test_kernel_shape_reasons():
     s = vd.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, skips=[4])
     assert s._kernel_takes() and s.precision == "fp32"
     assert not vd.DNeRF_Straightforward(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, skips=[2, 5])._kernel_takes()
+
+
+def test_precision_flags_reach_the_modules(monkeypatch):
+    """create_nerf / create_dnerf take the kernels' arithmetic from `args.precision` / `args.train_precision` when the
+    caller's parser has them, else from NRF_PRECISION / NRF_TRAIN_PRECISION; a mode a module does not have is refused."""
+    import types
+
+    import pytest
+
+    from nerf_amd import _setup
+    from nerf_amd.network import NeRF
+    from nerf_amd.vanilla_dynamic.network import DNeRF_Deformation
+    monkeypatch.delenv("NRF_PRECISION", raising=False)
+    monkeypatch.delenv("NRF_TRAIN_PRECISION", raising=False)
+    a, b = NeRF(D=2, W=64), NeRF(D=2, W=64)
+    assert _setup.apply_precision(types.SimpleNamespace(), a, None, b) == {}
+    assert (a.precision, a.train_precision) == ("fp32", "fp32")
+    _setup.apply_precision(types.SimpleNamespace(precision="bf16x3", train_precision="bf16x3_w16"), a, None, b)
+    assert (a.precision, a.train_precision, b.train_precision) == ("bf16x3", "bf16x3_w16", "bf16x3_w16")
+    monkeypatch.setenv("NRF_TRAIN_PRECISION", "bf16x3_a16")
+    c = NeRF(D=2, W=64)
+    assert _setup.apply_precision(types.SimpleNamespace(train_precision=None), c) == {"train_precision": "bf16x3_a16"}
+    assert (c.precision, c.train_precision) == ("fp32", "bf16x3_a16")
+    with pytest.raises(ValueError, match="train_precision"):
+        _setup.apply_precision(types.SimpleNamespace(), DNeRF_Deformation(D=2, W=64, D_deform=2, W_deform=64))
+    with pytest.raises(ValueError, match="precision 'fp64'"):
+        _setup.apply_precision(types.SimpleNamespace(precision="fp64"), NeRF(D=2, W=64))
