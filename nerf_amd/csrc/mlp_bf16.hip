@@ -728,9 +728,25 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16_kernel(const Bf16Args a
 // reference the raw outputs differ by ~1e-5 of their scale (bf16 alone: 5e-3), i.e. the f32 parity bar, at a third of the
 // bf16 kernel's point rate -- still ~3x the f32-MFMA kernel, whose matrix rate equals the vector rate on this chip.
 // One 32-point tile per wave (the accumulators are shared by the three products), four waves per workgroup.
+// The residuals a - float(hi.lo), b - float(hi.hi) come from v_dot2c_f32_bf16 against the pairs (-1, 0) and (0, -1) with a
+// and b as the accumulators: one operation a value instead of an unpack and a subtract, and exact (the product by -1 and the
+// sum are; `scripts/microbench/dot2bf.hip`: 0 mismatches in 2^20 values over 40 binades).  The pairs must NOT be compile-time
+// constants: (-1, 0) would be emitted as the inline constant -1.0, which this instruction reads as the f32 bit pattern
+// 0xBF800000 -- the pair (0, -1) -- so half the residuals come out as a - float(hi.hi) (the reason an earlier attempt at
+// bias row sums through this instruction was 14 % off).  They live in non-const __constant__ memory.
+#ifndef NRF_X3_SPLIT_DOT2
+#define NRF_X3_SPLIT_DOT2 1
+#endif
+__constant__ uint32_t nrf_split_neg[2] = {0x0000BF80u, 0xBF800000u};
 __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t &lo) {
     hi = pack2(a, b);
+#if NRF_X3_SPLIT_DOT2
+    const bf16x2 h = __builtin_bit_cast(bf16x2, hi);
+    lo = pack2(__builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, nrf_split_neg[0]), a, false),
+               __builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, nrf_split_neg[1]), b, false));
+#else
     lo = pack2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+#endif
 }
 
 // Training mode (nrf_query_fwd_train_bf16x3): where a wave's 32-point tile saves what the backward pass needs, in the f32
