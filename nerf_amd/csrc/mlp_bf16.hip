@@ -779,11 +779,12 @@ __device__ __forceinline__ void quad_transpose(uint32_t (&a)[4], int lane) {
     }
 }
 
-// 16-byte stores one call of store_tile_t8_quads per tile issues for nt tiles (the allowance of stream_frags)
+// 16-byte stores one call of store_tile_t8_quads (4 a tile) or store_tile_p16 (2 a tile) issues for nt tiles (the allowance of
+// stream_frags: a LOWER bound is safe, an overestimate is not)
 #ifndef NRF_X3_STORE_ALLOWANCE
 #define NRF_X3_STORE_ALLOWANCE 1
 #endif
-constexpr int x3_tile_stores(int nt) { return (NRF_X3_QUAD_STORES && NRF_X3_STORE_ALLOWANCE) ? 4 * nt : 0; }
+constexpr int x3_tile_stores(int nt, bool p16 = false) { return (NRF_X3_QUAD_STORES && NRF_X3_STORE_ALLOWANCE) ? (p16 ? 2 : 4) * nt : 0; }
 
 // One accumulator tile (16 values a lane, register r = channel 32t + (r&3) + 8(r>>2) + 4h of point lane&31) to its T8
 // section.  A T8 line is four channels of eight points: the four registers of a group (r>>2) of a lane quad hold a 4x4
@@ -804,45 +805,30 @@ __device__ __forceinline__ void store_tile_t8_quads(__amdgpu_buffer_rsrc_t rsrc,
     }
 }
 
-// The same tile as f16 (TrainLayout::half_acts, training mode "a16"): after the quad transpose a lane's four consecutive
-// points of one channel are two packed f16 pairs -- one 8-byte store.  nonneg: the values went through a ReLU, so the
-// saturation at 65504 (an infinity among the saved activations would turn a weight gradient into NaN) is one unsigned
-// 16-bit min per pair; the one section without a ReLU (feature_linear) clamps in f32 first.
-__device__ __forceinline__ void quad_transpose_h_step1(uint32_t &p0, uint32_t &p1, bool o2);
-__device__ __forceinline__ void quad_transpose_h_step2(uint32_t &p0, uint32_t &p1, uint32_t sel);
-__device__ __forceinline__ uint32_t quad_transpose_h_sel(int lane);
-__device__ __forceinline__ void store_tile_t8_quads_h(__amdgpu_buffer_rsrc_t rsrc, int lane, int C, uint32_t sec, int t,
-                                                      const float (&r)[16], bool nonneg) {
-    const int q = lane & 31, h = lane >> 5;
-    const int voff = (((q >> 3) * C + 4 * h + (q & 3)) * 8 + (q & 4)) * 2;
-    const bool o2 = lane & 2;
-    const uint32_t sel = quad_transpose_h_sel(lane);
-    uint32_t p[8];
-    // convert first (this lane's point, channel pairs), then transpose the PACKED pairs inside the lane quad: 8 operations a
-    // group where the f32 transpose took 16
+// The f16 sections (TrainLayout::half_acts / half_grads, training modes "a16" / "w16") are POINT-major ("P16"): per 32-point
+// tile and 32-channel tile ct two 1 KiB blocks j = 0, 1 of [point n (32)][lane half h (2)][8 values], value e of (ct, j, h)
+// being accumulator register 8 j + e of that lane half, i.e. channel 32 ct + ((8j+e) & 3) + 8 ((8j+e) >> 2) + 4 h:
+//     byte offset in the section = ((2 ct + j) * 32 + n) * 32 + 16 h + 2 e,    section = 64 C bytes.
+// A lane's eight registers 8j .. 8j+7 ARE one 16-byte piece and a wave's store is one contiguous KiB: no transpose, two
+// stores a tile (the channel-major T8 form cost a 4x4 transpose per lane quad and register group: 8 operations even on packed
+// pairs -- a quarter of the training conversion's VALU work -- and four 8-byte stores).  The price is paid where there is
+// slack: the weight-gradient GEMMs, which contract over POINTS, read their operands with ds_read_b64_tr_b16 (mlp_bwd.hip).
+// nonneg: the values went through a ReLU, so the saturation at 65504 (an infinity among the saved activations would turn a
+// weight gradient into NaN) is one unsigned 16-bit min per pair; otherwise a clamp in f32 first.
+__device__ __forceinline__ void store_tile_p16(__amdgpu_buffer_rsrc_t rsrc, int lane, uint32_t sec, int t, const float (&r)[16],
+                                               bool nonneg) {
+    const int voff = (lane & 31) * 32 + (lane >> 5) * 16;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (nonneg) {
-            p[2 * g] = sat2h(pack2h(r[4 * g], r[4 * g + 1]));
-            p[2 * g + 1] = sat2h(pack2h(r[4 * g + 2], r[4 * g + 3]));
-        } else {
-            p[2 * g] = pack2h(__builtin_amdgcn_fmed3f(r[4 * g], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(r[4 * g + 1], -65504.0f, 65504.0f));
-            p[2 * g + 1] = pack2h(__builtin_amdgcn_fmed3f(r[4 * g + 2], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(r[4 * g + 3], -65504.0f, 65504.0f));
+    for (int j = 0; j < 2; ++j) {
+        uint32_t p[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = r[8 * j + 2 * w], b = r[8 * j + 2 * w + 1];
+            if (nonneg) p[w] = sat2h(pack2h(a, b));
+            else p[w] = pack2h(__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f));
         }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) quad_transpose_h_step1(p[2 * g], p[2 * g + 1], o2);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) quad_transpose_h_step2(p[2 * g], p[2 * g + 1], sel);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
-        const u32x2s v = {p[2 * g], p[2 * g + 1]};
-#ifdef NRF_EXP_NOSTORE      // timing experiment: the conversion without its stores
-        asm volatile("" ::"v"(v));
-#else
-        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, (int)(sec * 4 + (32 * t + 8 * g) * 8 * 2), 0);
-#endif
+        const u32x4 v = {p[0], p[1], p[2], p[3]};
+        buffer_store_b128(v, rsrc, voff, (int)(sec * 4 + (2 * t + j) * 1024));
     }
 }
 
@@ -872,7 +858,7 @@ __device__ __forceinline__ void pack_acts_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl)[
         }
         if constexpr (TRAIN) {
 #if NRF_X3_QUAD_STORES
-            if constexpr (TRAIN == 2) store_tile_t8_quads_h(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r, relu);
+            if constexpr (TRAIN == 2) store_tile_p16(sv->tb.rsrc, sv->lane, sec, t, r, relu);
             else store_tile_t8_quads(sv->tb.rsrc, sv->lane, 32 * NT, sec, t, r);
 #else
             static_assert(TRAIN != 2, "the f16 workspace is written by the quad stores");
@@ -952,23 +938,6 @@ __device__ __forceinline__ void quad_transpose_part(uint32_t (&a)[4], bool o1, b
     }
 }
 
-// The 4x4 transpose of a lane quad on PACKED 16-bit pairs (lane i: p0 = channels 0, 1, p1 = channels 2, 3 of its point ->
-// p0 = points 0, 1, p1 = points 2, 3 of channel i): a dword exchange with lane i ^ 2, then a half-word exchange with lane
-// i ^ 1 through v_perm_b32 -- 8 operations where the f32 transpose followed by the conversion takes 16.
-__device__ __forceinline__ void quad_transpose_h_step1(uint32_t &p0, uint32_t &p1, bool o2) {
-    const uint32_t s = o2 ? p0 : p1;
-    const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    p0 = o2 ? got : p0;
-    p1 = o2 ? p1 : got;
-}
-__device__ __forceinline__ void quad_transpose_h_step2(uint32_t &p0, uint32_t &p1, uint32_t sel) {
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    const uint32_t g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0xB1, 0xF, 0xF, true);
-    p0 = __builtin_amdgcn_perm(g0, p0, sel);
-    p1 = __builtin_amdgcn_perm(g1, p1, sel);
-}
-__device__ __forceinline__ uint32_t quad_transpose_h_sel(int lane) { return (lane & 1) ? 0x03020706u : 0x05040100u; }
-
 // State of a forward conversion across its micro-slices (registers; only one or two groups' worth is live at a time).
 // TRAIN as in pack_acts_x3; RELU: the layer has one; GATE: its gate bits are saved (training).
 template <int TRAIN, bool RELU, bool GATE>
@@ -982,7 +951,6 @@ struct ConvFwd {
     int C;               // channels of the section
     int lane, voff;
     bool o1, o2;
-    uint32_t sel;
     float r[16], ta[4], tb[4];
     uint32_t p[8], gm[4], bits;
 
@@ -991,9 +959,8 @@ struct ConvFwd {
             rsrc = sv->tb.rsrc;
             lane = sv->lane;
             const int q = lane & 31, h = lane >> 5;
-            voff = (((q >> 3) * C_ + 4 * h + (q & 3)) * 8 + (q & 4)) * (TRAIN == 2 ? 2 : 4);
+            voff = TRAIN == 2 ? q * 32 + h * 16 : (((q >> 3) * C_ + 4 * h + (q & 3)) * 8 + (q & 4)) * 4;
             o1 = lane & 1; o2 = lane & 2;
-            sel = quad_transpose_h_sel(lane);
             sec = sec_;
             asm volatile("" : "+s"(sec));
             gate_slot = (uint32_t)gate_slot_;
@@ -1021,9 +988,10 @@ struct ConvFwd {
     // stores issued by micro-slice u of tile T (of NT_IN tiles)
     static constexpr int stores(int T, int u, int NT_IN) {
         if (TRAIN == 0) return 0;
-        return (u % 12 == kStoreStage ? 1 : 0) + (kGate && T == NT_IN - 1 && u == kConvSlices - 1 ? 1 : 0);
+        const bool st = TRAIN == 2 ? (u % 12 == 10 && ((u / 12) & 1)) : u % 12 == kStoreStage;
+        return (st ? 1 : 0) + (kGate && T == NT_IN - 1 && u == kConvSlices - 1 ? 1 : 0);
     }
-    static constexpr int stores_per_tile() { return TRAIN == 0 ? 0 : 4; }
+    static constexpr int stores_per_tile() { return TRAIN == 0 ? 0 : (TRAIN == 2 ? 2 : 4); }
 };
 
 // micro-slice U (0..47) of the conversion of accumulator tile T into operand k-steps 2T, 2T+1 (hh, hl).  T and U are template
@@ -1063,17 +1031,13 @@ __device__ __forceinline__ void conv_slice(CV &c, u32x4v (&hh)[2 * NT], u32x4v (
             if constexpr (g == 3) c.gm[T >> 1] = (T & 1) ? c.bits : (c.bits << 16);
         }
     } else if constexpr (TRAIN == 2) {
+        // P16 (store_tile_p16): registers 8j .. 8j+7 = groups 2j, 2j+1 are one 16-byte piece
         uint32_t &p0 = c.p[2 * g], &p1 = c.p[2 * g + 1];
         if constexpr (stg == 7) {
             c.template cvt_h<g>(p0, p1);
-        } else if constexpr (stg == 8) {
-            quad_transpose_h_step1(p0, p1, c.o2);
-        } else if constexpr (stg == 9) {
-            quad_transpose_h_step2(p0, p1, c.sel);
-        } else if constexpr (stg == 10) {
-            typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
-            const u32x2s v = {p0, p1};
-            __builtin_amdgcn_raw_buffer_store_b64(v, c.rsrc, c.voff, (int)(c.sec * 4 + (32 * T + 8 * g) * 8 * 2), 0);
+        } else if constexpr (stg == 10 && (g & 1)) {
+            const u32x4 v = {c.p[2 * g - 2], c.p[2 * g - 1], p0, p1};
+            buffer_store_b128(v, c.rsrc, c.voff, (int)(c.sec * 4 + (2 * T + (g >> 1)) * 1024));
         }
     } else if constexpr (TRAIN == 1) {
         uint32_t a[4] = {__float_as_uint(c.r[4 * g]), __float_as_uint(c.r[4 * g + 1]), __float_as_uint(c.r[4 * g + 2]),
@@ -1273,19 +1237,31 @@ __device__ __forceinline__ void save_pe3_t8(const X3Save &sv, uint32_t sec, cons
     constexpr int NF = (8 * KS - 2) / 6;
     static_assert(6 * NF <= KS32 - 2, "the f32 k-step list must hold every frequency pair");
     const int h = sv.tb.h;
-    const int voff = ((sv.tb.m * (2 * KS32) + h) * 8 + sv.tb.q7) * (HALF ? 2 : 4);
     asm volatile("" : "+s"(sec));
+    auto val = [&](int st) {
+        float r = 0.0f;
+        if (st < 6 * NF) r = v[2 + st];
+        else if (st == KS32 - 2) r = h ? y : x;
+        else if (st == KS32 - 1) r = h ? 0.0f : z;
+        return r;
+    };
+    if constexpr (HALF) {
+        // P16 (store_tile_p16): the lane's k-steps 8 pi .. 8 pi + 7 are one 16-byte piece, block (ct, j) = (pi >> 1, pi & 1);
+        // the column of the weight-gradient GEMM that reads it is k-step-space channel 2 st + h (wgrad_kernel's epilogue).
+        // Encoder values lie in [-1, 1], raw coordinates are scene-sized: no saturation needed
+        static_assert(KS32 % 16 == 0, "whole 32-channel tiles");
+        const int voff = (sv.lane & 31) * 32 + (sv.lane >> 5) * 16;
 #pragma unroll
-    for (int st = 0; st < KS32; ++st) {
-        float val = 0.0f;
-        if (st < 6 * NF) val = v[2 + st];
-        else if (st == KS32 - 2) val = h ? y : x;
-        else if (st == KS32 - 1) val = h ? 0.0f : z;
-        if constexpr (HALF)     // encoder values lie in [-1, 1], raw coordinates are scene-sized: no saturation needed
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2h(val, 0.0f) & 0xffffu), sv.tb.rsrc, voff,
-                                                  (int)(sec * 4 + 2 * st * 8 * 2), 0);
-        else
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), sv.tb.rsrc, voff, (int)((sec + 2 * st * 8) * 4), 0);
+        for (int pi = 0; pi < KS32 / 8; ++pi) {
+            const u32x4 p = {pack2h(val(8 * pi), val(8 * pi + 1)), pack2h(val(8 * pi + 2), val(8 * pi + 3)),
+                             pack2h(val(8 * pi + 4), val(8 * pi + 5)), pack2h(val(8 * pi + 6), val(8 * pi + 7))};
+            buffer_store_b128(p, sv.tb.rsrc, voff, (int)(sec * 4 + pi * 1024));
+        }
+    } else {
+        const int voff = ((sv.tb.m * (2 * KS32) + h) * 8 + sv.tb.q7) * 4;
+#pragma unroll
+        for (int st = 0; st < KS32; ++st)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val(st)), sv.tb.rsrc, voff, (int)((sec + 2 * st * 8) * 4), 0);
     }
 }
 
@@ -1298,7 +1274,7 @@ __device__ __forceinline__ void bf_trunk_x3(f32x16 (&acc)[NT], u32x4v (&hh)[2 * 
     gemm_layer_x3<NT, S0>(acc, st, b0h, b0l);
     pack_acts_x3<NT, TRAIN>(hh, hl, acc, true, sv, a_trunk, a_mask);
     for (int l = 1; l < n_trunk; ++l) {
-        constexpr int kSt = TRAIN ? x3_tile_stores(NT) : 0;   // the layer before saved its activations
+        constexpr int kSt = TRAIN ? x3_tile_stores(NT, TRAIN == 2) : 0;   // the layer before saved its activations
         if ((skip_in_mask >> l) & 1)
             gemm_layer_x3<NT, kBfKsX + 2 * NT, false, kSt>(
                 acc, st,
@@ -1353,7 +1329,7 @@ __device__ __forceinline__ void bf_views_head_x3(f32x16 (&acc)[NT], u32x4v (&hh)
                                                  int64_t n_points, int h, float *raw, const X3Save *sv = nullptr,
                                                  uint32_t a_feat = 0, uint32_t a_hv = 0, int hv_gate_slot = -1) {
     f32x16 acc1[1];
-    constexpr int kSt = TRAIN ? x3_tile_stores(NT) : 0;   // the last trunk layer saved its activations
+    constexpr int kSt = TRAIN ? x3_tile_stores(NT, TRAIN == 2) : 0;   // the last trunk layer saved its activations
     gemm_layer_x3<1, 2 * NT, false, kSt>(acc1, st, [&](int s) { return as_bf(hh[s]); }, [&](int s) { return as_bf(hl[s]); });  // network.py:56
     const float alpha = acc1[0][0] + hb[kHbAlpha];
     gemm_layer_x3<NT, 2 * NT + 1, true>(acc, st, [&](int s) { return s < 2 * NT ? as_bf(hh[s < 2 * NT ? s : 0]) : as_bf(one); },
@@ -1493,7 +1469,7 @@ __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl
             }
         }
 #if NRF_X3_QUAD_STORES
-        if constexpr (G16) store_tile_t8_quads_h(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r, false);
+        if constexpr (G16) store_tile_p16(tg.rsrc, (int)(threadIdx.x & 63), sec, t, r, false);
         else store_tile_t8_quads(tg.rsrc, (int)(threadIdx.x & 63), C, sec, t, r);
 #else
         static_assert(!G16, "the f16 gradient workspace is written by the quad stores");
@@ -1513,18 +1489,20 @@ __device__ __forceinline__ void finish_grad_x3(u32x4v (&hh)[2 * NT], u32x4v (&hl
     }
 }
 
-// store_head_tile (mlp_device.h) into an f16 section
-__device__ __forceinline__ void store_head_tile_h(const TBuf &tb, uint32_t sec, int C, int c0, const float (&vals)[8], int n) {
-    const int voff = ((tb.m * C + c0 + 16 * tb.h) * 8 + tb.q7) * 2;
+// store_head_tile (mlp_device.h) into an f16 (P16, store_tile_p16) section: rows o < n <= 8 of the 32-channel tile at channel
+// c0, zeros elsewhere.  Channel o sits in piece j = 0 of lane half (o >> 2) & 1 at element o & 3.
+__device__ __forceinline__ void store_head_tile_h(const TBuf &tb, uint32_t sec, int c0, const float (&vals)[8], int n, int lane) {
+    const int voff = (lane & 31) * 32 + (lane >> 5) * 16;
+    float v[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float v = 0.0f;
-#pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (tb.h == 0 && j == o && o < n) v = vals[o];
-        v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2h(v, 0.0f) & 0xffffu), tb.rsrc, voff, (int)(sec * 4 + j * 8 * 2), 0);
+    for (int e = 0; e < 4; ++e) {
+        const float a = e < n ? vals[e] : 0.0f, b = e + 4 < n ? vals[e + 4] : 0.0f;
+        v[e] = __builtin_amdgcn_fmed3f(tb.h ? b : a, -65504.0f, 65504.0f);
     }
+    const u32x4 p = {pack2h(v[0], v[1]), pack2h(v[2], v[3]), 0u, 0u};
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    buffer_store_b128(p, tb.rsrc, voff, (int)(sec * 4 + (c0 >> 5) * 2048));
+    buffer_store_b128(zero, tb.rsrc, voff, (int)(sec * 4 + (c0 >> 5) * 2048 + 1024));
 }
 
 struct DgradX3Args {
@@ -1583,7 +1561,7 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
             float4 gr = live ? reinterpret_cast<const float4 *>(a.g_raw)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (G16) { gr.x *= gs; gr.y *= gs; gr.z *= gs; gr.w *= gs; }
             const float hv3[8] = {gr.x, gr.y, gr.z, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_head, 32, 0, hv3, 3);
+            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_head, 0, hv3, 3, lane);
             else store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, hv3, 3);            // d/d(rgb logits): rgb_linear's wgrad
             {   // through rgb_linear (network.py:64) and the view layer's ReLU: three-term sums, on the VALU in f32
                 f32x16 g2[NT / 2];
@@ -1595,15 +1573,15 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
                 u32x4v vh[NT], vl[NT];
                 finish_grad_x3<NT / 2, false, true, false, G16>(vh, vl, g2, hvgate, wb, 0u, 0.f, tg, (uint32_t)tl.g_hv, W / 2);
                 // through views_linears[0][:, :W] (network.py:58-61) -> d/d(feature)
-                gemm_layer_x3<NT, NT, false, x3_tile_stores(NT / 2)>(acc, st, [&](int s) { return as_bf(vh[s]); },
+                gemm_layer_x3<NT, NT, false, x3_tile_stores(NT / 2, G16)>(acc, st, [&](int s) { return as_bf(vh[s]); },
                                                                      [&](int s) { return as_bf(vl[s]); });
             }
             finish_grad_x3<NT, true, false, false, G16>(hh, hl, acc, nogate, wb, 0u, 0.f, tg, (uint32_t)tl.g_feat, W + 32);
             const float ha[8] = {gr.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);
+            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_feat, W, ha, 1, lane);
             else store_head_tile(tg, (uint32_t)tl.g_feat, W + 32, W, ha, 1);          // d/d(alpha): alpha_linear's wgrad
             // through feature_linear and alpha_linear (network.py:56-57) -> d/d(h_{D-1}), then that layer's ReLU
-            gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT)>(acc, st, [&](int s) { return as_bf(hh[s]); },
+            gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT, G16)>(acc, st, [&](int s) { return as_bf(hh[s]); },
                                                                  [&](int s) { return as_bf(hl[s]); });
             finish_grad_x3<NT, true, true, true, G16>(hh, hl, acc, gate, wb, (uint32_t)pl.alpha_vec, gr.w, tg,
                                                       (uint32_t)tl.g_trunk + (pl.n_trunk - 1) * (gpw * W), W);
@@ -1611,7 +1589,7 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
             float ho[8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) ho[o] = (live && o < pl.output_ch) ? a.g_raw[p * pl.output_ch + o] * gs : 0.0f;
-            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
+            if constexpr (G16) store_head_tile_h(tg, (uint32_t)tl.g_head, 0, ho, pl.output_ch, lane);
             else store_head_tile(tg, (uint32_t)tl.g_head, 32, 0, ho, pl.output_ch);
             f32x16 g[NT];
             zero_acc<NT>(g);
@@ -1624,7 +1602,7 @@ __global__ void __launch_bounds__(256, 1) dgrad_x3_kernel(const DgradX3Args a) {
         // trunk in reverse (network.py:49-53): g_{l-1} = gate_{l-1} . (W_l[:, hidden]^T g_l)
         for (int l = pl.n_trunk - 1; l >= 1; --l) {
             gate = load_gate_bits(ta, (uint32_t)tl.a_mask + (l - 1) * 256, lane);       // in flight during the GEMM
-            gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT)>(acc, st, [&](int s) { return as_bf(hh[s]); },
+            gemm_layer_x3<NT, 2 * NT, false, x3_tile_stores(NT, G16)>(acc, st, [&](int s) { return as_bf(hh[s]); },
                                                                  [&](int s) { return as_bf(hl[s]); });
             finish_grad_x3<NT, true, true, false, G16>(hh, hl, acc, gate, wb, 0u, 0.f, tg, (uint32_t)tl.g_trunk + (l - 1) * (gpw * W), W);
         }

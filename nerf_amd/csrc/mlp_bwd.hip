@@ -296,6 +296,7 @@ struct WgradEntry {       // one nn.Linear's weight-gradient GEMM
     int64_t a_sec[2];        // X = section 0 (k_tiles0 tiles) followed by section 1
     int32_t Cg, Ca[2];       // channels in the T8 sections
     int32_t n_tiles, k_tiles, k_tiles0;  // 32-channel tiles of G (rows of dW) and of X (columns)
+    int32_t x_pe[2];         // f16 (P16) X sections: 1 = an encoded-input section (columns in k-step space), 0 = hidden
 };
 // ALL GEMMs of a backward pass in one launch: a block is (pair, chunk), a pair = (GEMM, super-block) -- pairs sorted
 // by tile count, largest first, so the skinny super-blocks (layer 0, the skip / view slices, the heads: HBM- and
@@ -405,6 +406,46 @@ __device__ __forceinline__ void wg_split(const f32x4 &p0, const f32x4 &p1, WgFra
     }
 }
 
+// ---- f16 sections are POINT-major ("P16", store_tile_p16 in mlp_bf16.hip): per 32-channel tile two 1 KiB blocks j = 0, 1 of
+// [point (32)][lane half h (2)][8 values].  A copy request brings 16 points of both blocks, eight lanes (128 contiguous
+// bytes: four points of one block) at a time, so the LDS image of a tile is units of 256 bytes: [4 points of j = 0][the same 4
+// points of j = 1] (eight lanes per 128-byte line; alternating single points between the blocks coalesces worse).  A
+// lane's MFMA fragment -- 8 consecutive points of ONE slot -- is two ds_read_b64_tr_b16: lane (j = (lane >> 4) & 1,
+// s = lane >> 5, i = lane & 15) passes the address of point row q = i >> 2 of its block, columns 4 (i & 3).., and receives
+// slot 16 j + i of points 8 s .. 8 s + 3 (the instruction's mapping verified with an indexed image,
+// scripts/microbench/tr_test.hip); the two 16-lane groups of a half read 128 contiguous bytes each, in disjoint banks.
+// MFMA row / column m = 16 j + 8 h + e of a tile is therefore NOT channel m: the epilogue permutes.
+// The reads are inline assembly: through the builtin the compiler cannot tell them from the in-flight LDS copies and puts
+// `s_waitcnt vmcnt(0)` in front of every group of them -- which drains the copy pipeline the counted waits exist for (w16
+// wgrad 2.69 -> 3.44 ms).  So the wait for the DATA is ours too: p16_wait() before the first use of a P16Frag.
+typedef uint32_t wg_u32x2 __attribute__((ext_vector_type(2)));
+struct P16Frag { wg_u32x2 lo, hi; };     // points 8s .. 8s+3, 8s+4 .. 8s+7 of the lane's slot
+__device__ __forceinline__ P16Frag p16_read8(const char *row0) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)row0;
+    P16Frag f;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(f.hi) : "v"(addr));
+    return f;
+}
+// (the fragment passes THROUGH the wait: a register copy of it cannot be scheduled in front)
+__device__ __forceinline__ void p16_wait(P16Frag &f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi)::"memory"); }
+__device__ __forceinline__ u32x4 p16_value(const P16Frag &f) {
+    const u32x4 v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return v;
+}
+// this lane's byte offset inside a tile image for the k-half it supplies (points 8 (lane >> 5) ..)
+__device__ __forceinline__ int p16_lane_off(int lane) {
+    return (lane >> 5) * 512 + ((lane >> 4) & 1) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8;
+}
+// per-lane source offset of a copy request inside a tile's 2 KiB of the section (16 points from point 0)
+__device__ __forceinline__ int p16_copy_off(int lane) { return ((lane >> 3) & 1) * 1024 + (lane >> 4) * 128 + (lane & 7) * 16; }
+// MFMA index m of a tile -> channel within the tile: hidden sections (accumulator order), encoded-input sections (k-step space)
+__device__ __forceinline__ int p16_chan_hidden(int m) {
+    const int r = 8 * (m >> 4) + (m & 7);
+    return (r & 3) + 8 * (r >> 2) + 4 * ((m >> 3) & 1);
+}
+__device__ __forceinline__ int p16_chan_input(int m) { return 2 * (8 * (m >> 4) + (m & 7)) + ((m >> 3) & 1); }
+
 // the same from eight f16 values (TrainLayout::half_acts): an f16 is exactly hi + lo (11 significant bits)
 typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
 // (The elements go through scalar copies: `__builtin_bit_cast(wg_f16x2, p[w])` on a vector ELEMENT expression took element 0
@@ -422,8 +463,8 @@ __device__ __forceinline__ void wg_split_h(const u32x4 p, WgFrag &f) {
     }
 }
 
-// XH: the X operand's sections hold f16 (a tile's piece of one 8-point group is 512 bytes: 32 channels x 8 points, and a
-// lane's fragment is ONE 16-byte read); G stays f32.
+// XH: the X operand's sections hold f16, point-major (P16 above): a tile's 16 points of a step are one 1 KiB copy and a
+// lane's fragment two transposing 8-byte reads; G stays f32.
 template <int NA, int KA, bool XH, class Req>
 __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
                                                int64_t nsteps, Req &&request) {
@@ -433,6 +474,11 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
     float R0[NAr], R1[NAr];                      // row sums of the G fragments (bias gradients)
     auto read_frags = [&](WgFrag (&A)[NAr], WgFrag (&B)[KAr], float (&R)[NAr], int stage) {
         const char *base = lds + stage * kWgStage + (lane >> 5) * 16384 + (lane & 31) * 16;
+        P16Frag xf[KAr];
+        if constexpr (XH) {         // the step's 16 points of X tile y: a 1 KiB P16 image in the first group's X area
+#pragma unroll
+            for (int y = 0; y < KA; ++y) xf[y] = p16_read8(lds + stage * kWgStage + 8192 + (kt0 + y) * 1024 + p16_lane_off(lane));
+        }
 #pragma unroll
         for (int x = 0; x < NA; ++x) {
             const f32x4 p0 = *reinterpret_cast<const f32x4 *>(base + (nt0 + x) * 1024);
@@ -443,8 +489,8 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
 #pragma unroll
         for (int y = 0; y < KA; ++y) {
             if constexpr (XH) {
-                const u32x4 raw = *reinterpret_cast<const u32x4 *>(base + 8192 + (kt0 + y) * 512);
-                wg_split_h(raw, B[y]);
+                p16_wait(xf[y]);
+                wg_split_h(p16_value(xf[y]), B[y]);
             } else {
                 const f32x4 p0 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024);
                 const f32x4 p1 = *reinterpret_cast<const f32x4 *>(base + (8 + kt0 + y) * 1024 + 512);
@@ -519,27 +565,27 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
 // loop is bound by how many copies are in flight, so it is laid out for that (the first version kept the x3 loop's shape --
 // 16 points a step, copies one step ahead, vmcnt(0) -- and ran at 3.6 TB/s with the matrix pipe 19 % busy):
 //   * a step is a whole 32-point tile (four 8-point groups, two MFMAs per tile pair): half the barriers;
-//   * FOUR LDS stages of 32 KiB (per group: G tiles at x * 512, X tiles at 4096 + y * 512; a 1 KiB copy brings two adjacent
-//     tiles), copies FOUR steps ahead (the running step's operands sit in registers, so its stage is free), and the wait
+//   * FOUR LDS stages of 32 KiB (G tile images at x * 2048, X tile images at 16384 + y * 2048; a 1 KiB copy brings 16 points of
+//     one tile), copies FOUR steps ahead (the running step's operands sit in registers, so its stage is free), and the wait
 //     before the barrier is COUNTED: vector-memory operations retire in order, so vmcnt(2 * nd) -- nd = this wave's copies
 //     per step -- returns when the step about to be read has landed and leaves the two younger steps in flight: 32 to 48 KiB
 //     per CU, 8 to 12 MiB over the chip.
 // Bias gradients = row sums of the G fragments (f32 adds).
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
-constexpr int kHStage = 32768, kHStages = 4, kHGroup = 8192;
+constexpr int kHStage = 32768, kHStages = 4, kHX = 16384;     // a stage: 8 G tile images of 2 KiB, then 8 X tile images
 template <int NA, int KA, class Req>
 __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
                                               int64_t nsteps, int nd, Req &&request) {
     constexpr int NAr = NA ? NA : 1, KAr = KA ? KA : 1;
-    u32x4 A0[2][NAr], B0[2][KAr], A1[2][NAr], B1[2][KAr];
-    auto read_frags = [&](u32x4 (&A)[2][NAr], u32x4 (&B)[2][KAr], int stage) {
+    P16Frag A0[2][NAr], B0[2][KAr], A1[2][NAr], B1[2][KAr];
+    auto read_frags = [&](P16Frag (&A)[2][NAr], P16Frag (&B)[2][KAr], int stage) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {        // k-block kb of the tile's 32 points: groups 2 kb (lanes 0-31) and 2 kb + 1
-            const char *base = lds + stage * kHStage + (2 * kb + (lane >> 5)) * kHGroup + (lane & 31) * 16;
+        for (int kb = 0; kb < 2; ++kb) {        // k-block kb: points 16 kb .. 16 kb + 15 of the tile images (rows of 64 bytes)
+            const char *base = lds + stage * kHStage + kb * 1024 + p16_lane_off(lane);
 #pragma unroll
-            for (int x = 0; x < NA; ++x) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + (nt0 + x) * 512); A[kb][x] = v; }
+            for (int x = 0; x < NA; ++x) A[kb][x] = p16_read8(base + (nt0 + x) * 2048);
 #pragma unroll
-            for (int y = 0; y < KA; ++y) { const u32x4 v = *reinterpret_cast<const u32x4 *>(base + 4096 + (kt0 + y) * 512); B[kb][y] = v; }
+            for (int y = 0; y < KA; ++y) B[kb][y] = p16_read8(base + kHX + (kt0 + y) * 2048);
         }
     };
     // own copies of the step about to be read have landed (`younger` later steps may stay in flight); after the barrier
@@ -557,13 +603,21 @@ __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4
         asm volatile("" ::: "memory");
     };
     int st_nxt = 1, st_req = 0;
-    auto body = [&](int64_t step, u32x4 (&A)[2][NAr], u32x4 (&B)[2][KAr], u32x4 (&An)[2][NAr], u32x4 (&Bn)[2][KAr]) {
+    auto body = [&](int64_t step, P16Frag (&A)[2][NAr], P16Frag (&B)[2][KAr], P16Frag (&An)[2][NAr], P16Frag (&Bn)[2][KAr]) {
         // requests issued so far: steps <= step + 3; the one read now is step + 1
         const int64_t last = nsteps - 1 < step + 3 ? nsteps - 1 : step + 3;
         land(last > step + 1 ? (int)(last - (step + 1)) : 0);
         // stage (step + 4) % 4 is this step's own: its fragments went to registers a step ago, and every wave is past that read
         if (step + 4 < nsteps) request(step + 4, st_req);
         if constexpr (NA > 0 && KA > 0) {
+            // this step's fragments were read a step ago by inline assembly: the wait for them is ours
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int x = 0; x < NA; ++x) p16_wait(A[kb][x]);
+#pragma unroll
+                for (int y = 0; y < KA; ++y) p16_wait(B[kb][y]);
+            }
             read_frags(An, Bn, st_nxt);     // past the last step this re-reads a stale stage: unused
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -571,17 +625,18 @@ __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4
 #pragma unroll
                 for (int x = 0; x < NA; ++x) {
                     float r = 0.0f;
+                    const u32x4 av = p16_value(A[kb][x]);
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const uint32_t e = A[kb][x][w];   // a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0
+                        const uint32_t e = av[w];   // a scalar copy first: __builtin_bit_cast of a vector ELEMENT reads element 0
                         const wg_f32x2 v = __builtin_convertvector(__builtin_bit_cast(wg_f16x2, e), wg_f32x2);
                         r += v[0] + v[1];
                     }
                     bs[x] += r;
 #pragma unroll
                     for (int y = 0; y < KA; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, A[kb][x]),
-                                                                          __builtin_bit_cast(wg_f16x8, B[kb][y]), acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, av),
+                                                                          __builtin_bit_cast(wg_f16x8, p16_value(B[kb][y])), acc[x][y], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -657,7 +712,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
     const int64_t t1 = min(b.ntiles, t0 + b.chunk_tiles);
     constexpr int kSpt = GH ? 1 : 4 / kWgM;        // steps per 32-point tile
     const int64_t nsteps = (t1 - t0) * kSpt;       // one step = kWgM groups of 8 points of one tile (GH: the whole tile)
-    // GH: wave w copies G tile pair w and X tile pair w of all four point groups: 4 copies each
+    // GH: wave w copies G tiles 2w, 2w+1 and X tiles 2w, 2w+1 (two 16-point copies each): 4 copies a side
     const bool h_g = 2 * wib < gn, h_x = 2 * wib < xn;
     const int nd = GH ? 4 * ((int)h_g + (int)h_x) : 0;
 
@@ -666,27 +721,32 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
         const int64_t tile = t0 + step / kSpt;
         const int m0 = (int)(step % kSpt) * kWgM;
         if constexpr (GH) {
-            // both sides f16: a 1 KiB copy = two adjacent 32-channel tiles of one 8-point group (64 channels x 16 bytes;
-            // lanes beyond the section read zeros or a tile no fragment uses)
-            char *dst = lds + stage * kHStage + wib * 1024;
+            // both sides f16, point-major: a 1 KiB copy = 16 points of one 32-channel tile (p16_copy_off); a tile beyond its
+            // section reads zeros.  Wave w: G tiles 2w, 2w+1 and X tiles 2w, 2w+1, two copies each
+            const int csrc = p16_copy_off(lane);
             if (h_g) {
                 __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(gbuf) + tile * g_tile + a.g_sec, 0, a.Cg * 32 * 2, 0x00020000);
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(dst + m * kHGroup), 16,
-                                                             lane * 16, ((m * a.Cg + 32 * (nsb * 8 + 2 * wib)) * 8) * 2, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const int x = 2 * wib + (u >> 1), half = u & 1;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rg, (__attribute__((address_space(3))) void *)(lds + stage * kHStage + x * 2048 + half * 1024), 16, csrc,
+                        (nsb * 8 + x) * 2048 + half * 512, 0, 0);
+                }
             }
             if (h_x) {
-                const int kt = ksb * 8 + 2 * wib;
-                const int sec = kt >= a.k_tiles0;
-                const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
-                __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float *>(acts) + tile * a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 2, 0x00020000);
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dst + 4096 + m * kHGroup),
-                                                             16, lane * 16, ((m * a.Ca[sec] + c0) * 8) * 2, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const int y = 2 * wib + (u >> 1), half = u & 1;
+                    const int kt = ksb * 8 + y;
+                    const int sec = kt >= a.k_tiles0;
+                    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(acts) + tile * a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 2, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rx, (__attribute__((address_space(3))) void *)(lds + stage * kHStage + kHX + y * 2048 + half * 1024), 16, csrc,
+                        (sec ? kt - a.k_tiles0 : kt) * 2048 + half * 512, 0, 0);
+                }
             }
             return;
         }
@@ -703,20 +763,16 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
                                                              16, lane_src,
                                                              (((m0 + mm) * a.Cg + 32 * (nsb * 8 + i)) * 8) * 4, 0, 0);
             } else if (XH) {
-                // f16 X sections: one 1 KiB copy = TWO adjacent 32-channel tiles of one 8-point group (64 channels x 16 bytes;
-                // lanes beyond the section read zeros or a tile no fragment uses)
-                const int j = i - 8;
-                if (i >= 8 && 2 * j < xn) {
-                    const int kt = ksb * 8 + 2 * j;
+                // f16 X sections, point-major: one 1 KiB copy = the step's 16 points of one 32-channel tile (p16_copy_off),
+                // into the first group's X area (8 tiles x 1 KiB)
+                if (i >= 8 && i - 8 < xn) {
+                    const int kt = ksb * 8 + (i - 8);
                     const int sec = kt >= a.k_tiles0;
-                    const int c0 = 32 * (sec ? kt - a.k_tiles0 : kt);
                     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<float *>(acts) + tile * a_tile + a.a_sec[sec], 0, a.Ca[sec] * 32 * 2, 0x00020000);
-                    char *dx = lds + stage * kWgStage + 8192 + j * 1024;
-#pragma unroll
-                    for (int mm = 0; mm < kWgM; ++mm)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dx + mm * 16384),
-                                                                 16, lane * 16, (((m0 + mm) * a.Ca[sec] + c0) * 8) * 2, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rx, (__attribute__((address_space(3))) void *)(lds + stage * kWgStage + 8192 + (i - 8) * 1024), 16,
+                        p16_copy_off(lane), (sec ? kt - a.k_tiles0 : kt) * 2048 + m0 * 8 * 32, 0, 0);
                 }
             } else if (i - 8 < xn && i >= 8) {
                 const int kt = ksb * 8 + (i - 8);
@@ -766,15 +822,20 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WgradArgs b_arg) {
 #pragma unroll
             for (int y = 0; y < 4; ++y)
                 if (y < ka) {
+                    // f16 (P16) operands: MFMA row / column m is not channel m (p16_chan_*): a permutation inside the tile
+                    int col = lane & 31;
+                    if constexpr (XH) col = ea.x_pe[(k0 + y) >= a.k_tiles0] ? p16_chan_input(col) : p16_chan_hidden(col);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        int row = 32 * (n0 + x) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        slab[(int64_t)row * KP + 32 * (k0 + y) + (lane & 31)] = acc[x][y][r];
+                        int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if constexpr (GH) mrow = p16_chan_hidden(mrow);
+                        slab[(int64_t)(32 * (n0 + x) + mrow) * KP + 32 * (k0 + y) + col] = acc[x][y][r];
                     }
                 }
             if (k0 == 0) {
                 float v = bs[x] + __shfl_xor(bs[x], 32);
-                if (lane < 32) a.slab[(int64_t)b.nchunks * NP * KP + (int64_t)chunk * NP + 32 * (n0 + x) + lane] = v;
+                const int brow = GH ? p16_chan_hidden(lane & 31) : lane;
+                if (lane < 32) a.slab[(int64_t)b.nchunks * NP * KP + (int64_t)chunk * NP + 32 * (n0 + x) + brow] = v;
             }
         }
 }
@@ -1009,7 +1070,8 @@ struct Bwd {
         w.slab = region; w.g_sec = g_sec; w.Cg = Cg; w.n_tiles = n_tiles;
         w.a_sec[0] = xp[0].sec; w.Ca[0] = xp[0].C; w.k_tiles0 = xp[0].tiles; w.k_tiles = k_tiles;
         w.a_sec[1] = xp[0].sec; w.Ca[1] = xp[0].C;
-        if (nparts > 1) { w.a_sec[1] = xp[1].sec; w.Ca[1] = xp[1].C; }
+        w.x_pe[0] = w.x_pe[1] = xp[0].type != BLK_HIDDEN;
+        if (nparts > 1) { w.a_sec[1] = xp[1].sec; w.Ca[1] = xp[1].C; w.x_pe[1] = xp[1].type != BLK_HIDDEN; }
         slab_off += (int64_t)nchunks * ((int64_t)n_tiles * 32 * k_tiles * 32 + n_tiles * 32);
         if (slab_off > slab_cap) return nrf::fail(NRF_ERR_UNSUPPORTED, "nrf_query_bwd: slab workspace too small (internal)");
         for (int sb = 0; sb < n_sb * k_sb; ++sb) {

@@ -193,6 +193,26 @@ print("BUCKETED_OK")
     assert r.returncode == 0 and "BUCKETED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def p16_to_t8_index(sections):
+    """idx with t8_order = p16_order[idx] for a run of f16 workspace sections [(channels, kind)]: the f32 sections are
+    channel-major T8 (element (c, point q) at ((q >> 3) C + c) 8 + (q & 7)); the f16 ones are point-major: per 32-channel
+    tile ct two blocks j of [point][lane half h][8 values e], holding accumulator register 8j + e of half h -- channel
+    32 ct + ((8j+e) & 3) + 8 ((8j+e) >> 2) + 4 h of a hidden section, k-step-space channel 32 ct + 2 (8j+e) + h of an
+    encoded-input section."""
+    out, base = [], 0
+    for C, kind in sections:
+        idx = np.arange(32 * C, dtype=np.int64)
+        if kind is not None:
+            ct, j, n, h, e = np.meshgrid(np.arange(C // 32), np.arange(2), np.arange(32), np.arange(2), np.arange(8), indexing="ij")
+            r = 8 * j + e
+            c = 32 * ct + ((r & 3) + 8 * (r >> 2) + 4 * h if kind == "hidden" else 2 * r + h)
+            src = ((2 * ct + j) * 32 + n) * 16 + 8 * h + e
+            idx[(((n >> 3) * C + c) * 8 + (n & 7)).reshape(-1)] = src.reshape(-1)
+        out.append(idx + base)
+        base += 32 * C
+    return np.concatenate(out)
+
+
 @pytest.mark.parametrize("cfg", ["views256", "noview128", "views128_ragged"])
 def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
     """nrf_query_fwd_train_bf16x3 against nrf_query_fwd_train on the same net and points: raw within 5e-5 of its scale
@@ -264,7 +284,7 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
             e = float((grads_a[k] - grads_c[k]).abs().max())
             assert e <= 5e-5 * sc, (mode, k, e, sc)
     # "a16": the same forward saving its activations as f16 (nrf_query_fwd_train_bf16x3_a16) -- raw bit for bit, the
-    # workspace the f32 one rounded to f16 (2^-11 relative, element order unchanged, half the floats per section), gate
+    # workspace the f32 one rounded to f16 (2^-11 relative, point-major sections of half the floats), gate
     # words identical; nrf_query_bwd_bf16x3_a16 then differs from nrf_query_bwd_bf16x3 on the f32 workspace by that
     # rounding of the weight-gradient GEMMs' X operand alone: <= 1e-3 of each gradient's scale (measured ~2e-4)
     raw_c, acts_c = x3.query_train(pts, dirs, ppr, a16=True)
@@ -272,7 +292,10 @@ def test_bf16x3_training_forward_saves_the_f32_workspace(cfg):
     a_mask_h = a_mask // 2
     tile_h = a_mask_h + 256 * (D + 1)
     Cw = acts_c[:(P + 31) // 32 * tile_h].reshape(-1, tile_h)
-    fc = Cw[:n_full, :a_mask_h].contiguous().view(torch.float16).float()[:, keep]
+    # the f16 sections are POINT-major (P16, store_tile_p16 in mlp_bf16.hip): bring them back to the f32 workspace's order
+    perm = torch.from_numpy(p16_to_t8_index([(64, "input"), (32, "input"), (24, None)] + [(W, "hidden")] * (D + 1)
+                                            + [(W // 2, "hidden")])).cuda()
+    fc = Cw[:n_full, :a_mask_h].contiguous().view(torch.float16).float()[:, perm][:, keep]
     assert float(((fc - fb).abs() * live).max()) <= 6e-4 * float(fb.abs().max())
     assert torch.equal(Cw[:n_full, a_mask_h:].view(torch.int32)[:, :gb.shape[1]], gb)
     grads_x3 = f32.query_bwd(g_raw, P, acts_b, x3=True)
