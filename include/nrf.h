@@ -292,8 +292,9 @@ int nrf_query_bwd_bf16x3(const nrf_net_t *net, const nrf_embed_t *emb, const flo
 /* The bf16x3 training pass with the saved activations in f16 ("bf16x3_a16"; no counterpart in the reference): the step is
  * bound by the bytes of its workspaces, and the post-ReLU activations are what the forward writes and
  * the weight-gradient GEMMs read back.  nrf_query_fwd_train_bf16x3_a16 saves them (and the encoded inputs) as f16 --
- * round-to-nearest, saturating at 65504; same element order, two bytes a value, inside a workspace of the usual
- * nrf_train_acts_floats size -- and nrf_query_bwd_bf16x3_a16 (parameter gradients; `packed_bwd_x3` required) reads them as
+ * round-to-nearest, saturating at 65504; two bytes a value, each section point-major ("P16": per 32-channel tile two
+ * 1 KiB blocks j of [point 32][lane half 2][8 values], value e = accumulator register 8j + e of that lane half; DESIGN.md
+ * section 3), inside a workspace of the usual nrf_train_acts_floats size; the layout is private to this pair of calls -- and nrf_query_bwd_bf16x3_a16 (parameter gradients; `packed_bwd_x3` required) reads them as
  * exact hi + lo bf16 pairs.  Gradient blocks stay f32.  Forward results are those of nrf_query_fwd_train_bf16x3 bit for bit;
  * weight gradients carry the activations' f16 rounding (2^-12 per value: ~2e-4 of a gradient's norm against 2e-3, the
  * bar every training arithmetic is tested to).  Static nets, W = 128 / 256, embed mode 0. */

@@ -109,9 +109,10 @@ struct NetPlan {
 // (lane (s, c) takes the 4 points 8m+4s.. of channel c).
 struct TrainLayout {
     int32_t nt, n_trunk, use_viewdirs;
-    int32_t half_acts;               // 1: the activation sections (inputs, trunk, feature, view layer) hold f16 values -- same
-                                     // element order, two bytes each, so a section of C channels takes 16 * C floats (the
-                                     // bf16x3 training mode "a16": half the bytes the forward writes and wgrad reads back)
+    int32_t half_acts;               // 1: the activation sections (inputs, trunk, feature, view layer) hold f16 values, two
+                                     // bytes each and POINT-major (P16: store_tile_p16 in mlp_bf16.hip), so a section of C
+                                     // channels takes 16 * C floats (the bf16x3 training mode "a16": half the bytes the
+                                     // forward writes and wgrad reads back)
     // activations (floats from the tile's base)
     int64_t a_xin, a_din, a_tin;     // input blocks in k-step space: channel 2*step + half (64 / 32 / 24 ch)
     int64_t a_trunk;                 // D sections of W channels: post-ReLU outputs of trunk layer l
@@ -121,7 +122,7 @@ struct TrainLayout {
                                      // (D sections of W) and of the view layer: what the LayerNorm backward differentiates
     int64_t a_rstd;                  // LayerNorm nets only: D + 1 slots of 32 floats: 1 / sqrt(var + eps) of each point
     int64_t a_tile;                  // floats per tile
-    int32_t half_grads, pad2_;       // 1: the gradient sections g_trunk / g_feat / g_hv / g_head hold f16 values (pre-scaled by a
+    int32_t half_grads, pad2_;       // 1: the gradient sections g_trunk / g_feat / g_hv / g_head hold f16 values, P16 (pre-scaled by a
                                      // power of two, training mode "w16"): 16 * C floats per section of C channels
     // gradients w.r.t. pre-activations
     int64_t g_trunk;                 // D sections of W
