@@ -572,7 +572,10 @@ __device__ __forceinline__ void wgrad_steps_x3(f32x16 (&acc)[4][4], float (&bs)[
 //     per CU, 8 to 12 MiB over the chip.
 // Bias gradients = row sums of the G fragments (f32 adds).
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
-constexpr int kHStage = 32768, kHStages = 4, kHX = 16384;     // a stage: 8 G tile images of 2 KiB, then 8 X tile images
+#ifndef NRF_WG_H_STAGES
+#define NRF_WG_H_STAGES 4      // 5 (all 160 KiB of LDS, 64 KiB of copies in flight per CU): measured no change (2.72 vs 2.71 ms)
+#endif
+constexpr int kHStage = 32768, kHStages = NRF_WG_H_STAGES, kHX = 16384;     // a stage: 8 G tile images of 2 KiB, then 8 X tile images
 template <int NA, int KA, class Req>
 __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4], const char *lds, int lane, int nt0, int kt0,
                                               int64_t nsteps, int nd, Req &&request) {
@@ -597,18 +600,20 @@ __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
             case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
             case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;       // 3 * 8
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;       // 4 * 8
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
     int st_nxt = 1, st_req = 0;
     auto body = [&](int64_t step, P16Frag (&A)[2][NAr], P16Frag (&B)[2][KAr], P16Frag (&An)[2][NAr], P16Frag (&Bn)[2][KAr]) {
-        // requests issued so far: steps <= step + 3; the one read now is step + 1
-        const int64_t last = nsteps - 1 < step + 3 ? nsteps - 1 : step + 3;
+        // requests issued so far: steps <= step + kHStages - 1; the one read now is step + 1
+        const int64_t last = nsteps - 1 < step + kHStages - 1 ? nsteps - 1 : step + kHStages - 1;
         land(last > step + 1 ? (int)(last - (step + 1)) : 0);
-        // stage (step + 4) % 4 is this step's own: its fragments went to registers a step ago, and every wave is past that read
-        if (step + 4 < nsteps) request(step + 4, st_req);
+        // stage (step + kHStages) % kHStages is this step's own: its fragments went to registers a step ago, and every wave is
+        // past that read
+        if (step + kHStages < nsteps) request(step + kHStages, st_req);
         if constexpr (NA > 0 && KA > 0) {
             // this step's fragments were read a step ago by inline assembly: the wait for them is ours
 #pragma unroll
@@ -640,15 +645,14 @@ __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        st_nxt = (st_nxt + 1) & 3;
-        st_req = (st_req + 1) & 3;
+        st_nxt = st_nxt + 1 == kHStages ? 0 : st_nxt + 1;
+        st_req = st_req + 1 == kHStages ? 0 : st_req + 1;
     };
     if (nsteps > 0) {
-        request(0, 0);
-        if (nsteps > 1) request(1, 1);
-        if (nsteps > 2) request(2, 2);
-        if (nsteps > 3) request(3, 3);
-        land(nsteps > 3 ? 3 : (int)(nsteps - 1));
+#pragma unroll
+        for (int i = 0; i < kHStages; ++i)
+            if (i < nsteps) request(i, i);
+        land(nsteps > kHStages - 1 ? kHStages - 1 : (int)(nsteps - 1));
         if constexpr (NA > 0 && KA > 0) read_frags(A0, B0, 0);
     }
     for (int64_t step = 0; step < nsteps; step += 2) {
