@@ -2,6 +2,7 @@
 # same-box A/B of library variants: bf16x3 render and the w16 training step, two rounds
 R=$GRAFT_REPO_ROOT
 cp $R/nerf_amd/libnrf.so /tmp/libnrf_orig.so
+trap 'cp /tmp/libnrf_orig.so $R/nerf_amd/libnrf.so' EXIT     # leave the tree's own library in place
 for round in 1 2; do
 for v in orig "$@"; do
   if [ $v = orig ]; then cp /tmp/libnrf_orig.so $R/nerf_amd/libnrf.so; else cp $R/scratch/$v $R/nerf_amd/libnrf.so; fi

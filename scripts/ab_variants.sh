@@ -6,6 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cp $R/nerf_amd/libnrf.so /tmp/libnrf_orig.so
+trap 'cp /tmp/libnrf_orig.so $R/nerf_amd/libnrf.so' EXIT     # leave the tree's own library in place
 for round in 1 2; do
 for v in "$@"; do
   if [ $v = orig ]; then cp /tmp/libnrf_orig.so $R/nerf_amd/libnrf.so; else cp $R/scratch/$v $R/nerf_amd/libnrf.so; fi
