@@ -5,7 +5,7 @@ lego-style camera sphere.  train.py's loop (4096 random rays per step, 64 + 128 
 exponential decay) on the fused kernels; then a held-out 200x200 view rendered with the fp32, bf16x3 and bf16 kernels:
 PSNR against the analytic image (what the north star's 'PSNR delta <= 0.05 dB' speaks of), and the fp32 image against the
 CPU oracle on the trained weights.  Writes gpurun_out/<round>_trained_scene.json.
-    python scripts/train_synthetic_scene.py [round] [steps] [train_precision]"""
+    python scripts/train_synthetic_scene.py [round] [steps] [train_precision]        (NRF_SEED=n: another run)"""
 import json
 import os
 import sys
@@ -30,8 +30,9 @@ load = os.path.join(R, "gpurun_out", f"{sys.argv[1] if len(sys.argv) > 1 else 'r
     if len(sys.argv) > 4 and sys.argv[4] == "load" else None
 tprec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 dev = torch.device("cuda:0")
-torch.manual_seed(0)
-np.random.seed(0)
+seed = int(os.environ.get("NRF_SEED", "0"))      # initial weights and ray batches; the scene and its views stay the same
+torch.manual_seed(seed)
+np.random.seed(seed)
 
 
 def shade(ro, rd):
