@@ -13,7 +13,9 @@
 //   * alpha / rgb heads are one-output-tile GEMMs on the same stream;
 //   * gamma(x): one accurate sincosf per coordinate at the lane's base frequency, higher octaves by the
 //     double-angle recurrence (error ~2^-16, far below bf16's 2^-9 rounding of the encoded value).
-// Inference only; training stays on the exact f32 kernels.
+// The plain 16-bit kernels (bf16, f16) are inference only.  Further down: the bf16x3 kernels (three bf16 MFMAs per product on
+// hi/residual operands: f32-grade) -- inference, the training forward that saves its activations (f32 T8 or f16 P16
+// sections), and the activation-gradient chain; the weight-gradient GEMMs are in mlp_bwd.hip.
 #include "mlp_device.h"
 #include <stdlib.h>
 #include <utility>
@@ -832,7 +834,7 @@ __device__ __forceinline__ void store_tile_p16(__amdgpu_buffer_rsrc_t rsrc, int 
     }
 }
 
-// sec: T8 section (floats from the tile base) the f32 values are saved to; gate_slot >= 0: also the ReLU gate bits
+// sec: section (floats from the tile base; f32 T8 or f16 P16) the values are saved to; gate_slot >= 0: also the ReLU gate bits
 // (bit order of store_gate_bits).  The stores sit in the conversion phase, where the matrix pipe is idle anyway.
 // TRAIN: 0 inference, 1 save f32 (the exact kernels' workspace format), 2 save f16 (half_acts)
 template <int NT, int TRAIN = 0>
@@ -946,7 +948,7 @@ struct ConvFwd {
     static constexpr bool kGate = GATE && TRAIN != 0;
     static constexpr int kStoreStage = TRAIN == 2 ? 10 : 11;
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t sec;        // T8 section (floats from the tile base)
+    uint32_t sec;        // section (floats from the tile base): f32 T8 (TRAIN 1) or f16 P16 (TRAIN 2)
     uint32_t gate_slot;
     int C;               // channels of the section
     int lane, voff;
@@ -1432,7 +1434,8 @@ __global__ void __launch_bounds__(256, 1) query_fwd_bf16x3_kernel(const Bf16Args
 
 // ---- bf16x3 activation-gradient chain (the dgrad_kernel of mlp_bwd.hip on the bf16 matrix pipe) ------------------------
 // A gradient block on its way from one GEMM of the chain to the next: accumulators (or VGPR values) [+ sc * head vector]
-// -> ReLU gate -> saved in f32 to its T8 section of `gbuf` (what the weight-gradient GEMMs read) -> hi/residual operands.
+// -> ReLU gate -> saved to its section of `gbuf` (f32 T8, or f16 P16 with G16: what the weight-gradient GEMMs read) ->
+// hi/residual operands.
 // G16 (training mode "w16"): the saved copy is f16 (the chain's gradients are pre-scaled by a power of two so that the
 // step's largest |d(loss)/d(raw)| is in [2^10, 2^11); saturating at 65504) -- the chain's own operands keep their hi/residual pair.
 template <int NT, bool FROM_ACC, bool GATE, bool AXPY, bool G16 = false>

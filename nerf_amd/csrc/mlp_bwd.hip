@@ -294,7 +294,7 @@ struct WgradEntry {       // one nn.Linear's weight-gradient GEMM
     float *slab;         // [nchunks][NP*KP] partial dW, then [nchunks][NP] partial db
     int64_t g_sec;
     int64_t a_sec[2];        // X = section 0 (k_tiles0 tiles) followed by section 1
-    int32_t Cg, Ca[2];       // channels in the T8 sections
+    int32_t Cg, Ca[2];       // channels in the sections (f32 T8, or f16 P16)
     int32_t n_tiles, k_tiles, k_tiles0;  // 32-channel tiles of G (rows of dW) and of X (columns)
     int32_t x_pe[2];         // f16 (P16) X sections: 1 = an encoded-input section (columns in k-step space), 0 = hidden
 };
