@@ -659,6 +659,20 @@ __device__ __forceinline__ void wgrad_steps_h(f32x16 (&acc)[4][4], float (&bs)[4
         body(step, A0, B0, A1, B1);
         if (step + 1 < nsteps) body(step + 1, A1, B1, A0, B0);
     }
+    // The last step's read-ahead is still in flight and nobody uses it: to the compiler its destination registers are dead
+    // from here on, and an inline-assembly read that lands late would overwrite whatever they are reused for.  Keep them alive
+    // through a wait (every fragment passes through it).
+    if constexpr (NA > 0 && KA > 0) {
+        if (nsteps > 0) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int x = 0; x < NA; ++x) { p16_wait(A0[kb][x]); p16_wait(A1[kb][x]); }
+#pragma unroll
+                for (int y = 0; y < KA; ++y) { p16_wait(B0[kb][y]); p16_wait(B1[kb][y]); }
+            }
+        }
+    }
 }
 
 template <bool X3, bool XH = false, bool GH = false>
