@@ -1127,6 +1127,16 @@ using namespace nrf;
 // alone, so gradients stay bit-reproducible.
 // Measured (one box, ms per step f32 / bf16x3): 512 rays 4.45 / 2.64 with 256 chunks -> 4.02 / 2.07; 32, 64 and 128 tiles
 // per chunk within 1 %, 256 and more slower again (too few workgroups).
+// The bf16-pipe weight-gradient kernels are 2-4x faster than the f32 one, so the per-chunk costs (a 256 KiB slab written per
+// block and GEMM, read back by the reduction; the copy pipeline's fill and drain) weigh more: fewer, longer chunks.  Measured,
+// ms per 4096-ray step, wgrad + reduction: w16 2.92 / 2.83 / 2.69 / 2.55 / 2.67 / 2.64 at 256 / 192 / 128 / 64 / 48 / 32 chunks;
+// a16 4.73 / 4.60 / 4.73 at 256 / 128 / 64.
+#ifndef NRF_WG_H_MAXCHUNKS
+#define NRF_WG_H_MAXCHUNKS 64
+#endif
+#ifndef NRF_WG_X3_MAXCHUNKS
+#define NRF_WG_X3_MAXCHUNKS 128
+#endif
 constexpr int kWgChunkTiles = 64;
 static int64_t pick_chunks(int64_t ntiles, int *chunk_tiles, int max_chunks = 256) {
     int64_t want = std::max<int64_t>(32, ntiles / kWgChunkTiles);
@@ -1258,7 +1268,7 @@ dgrad_done:
     Bwd B{};
     B.net = net; B.grads = grads; B.pl = pl; B.tl = d.tl; B.acts = acts; B.gbuf = gbuf; B.slab = slab;
     B.ntiles = ntiles; B.st = st; B.x3 = x3; B.xh = half_acts; B.gmax = gmax;
-    B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, max_chunks);
+    B.nchunks = (int)pick_chunks(ntiles, &B.chunk_tiles, half_grads ? std::min(max_chunks, NRF_WG_H_MAXCHUNKS) : (x3 ? std::min(max_chunks, NRF_WG_X3_MAXCHUNKS) : max_chunks));
     B.slab_cap = slab_floats(net, n_points, max_chunks) - ln_partial_floats(net) - kGmaxFloats;
     if (pl.layernorm) {   // the affine parameters' gradients: independent of the weight-gradient GEMMs below
         LnGradArgs la{};
